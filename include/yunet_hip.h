@@ -1,0 +1,208 @@
+/*
+ * yunet_hip.h -- C ABI of libyunet_hip.so, the MI355X (gfx950) kernels of the YuNet
+ * training hot path.  Plain pointers and sizes only: every pointer is a DEVICE pointer
+ * unless stated otherwise, `stream` is a hipStream_t passed as void*, every function
+ * returns 0 on success or a negative YUNET_E* / the hipError_t of the failed launch.
+ * No ownership is transferred; nothing is allocated; nothing synchronises.
+ *
+ * The reference (ShiqiYu/libfacedetection.train) has no FFI: its drop-in boundary is
+ * the mmcv Registry.  The registered Python classes of
+ * libfacedetection.train_amd/ bind these entry points with ctypes; each entry point
+ * names the reference code it replaces (paths relative to the reference root).
+ *
+ * Layouts: activations are NHWC fp32; parameters keep the reference's OIHW fp32
+ * shapes (pointwise [Co,Ci,1,1], depthwise [C,1,3,3], stem [16,3,3,3]); images enter
+ * as the reference delivers them, NCHW fp32.
+ */
+#ifndef YUNET_HIP_H
+#define YUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YUNET_ABI_VERSION 1
+
+#define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
+#define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
+
+/* Train-mode BatchNorm description shared by producers and consumers.
+ * The producer of a tensor accumulates `stats` = {sum[C], sumsq[C]} (fp64) over all
+ * N*H*W positions; consumers derive scale = gamma*invstd, shift = beta - mean*scale in
+ * their prologue (nn.BatchNorm2d defaults, mmdet/models/utils/yunet_layer.py:26,60).
+ * In backward, consumers accumulate `bstats` = {sum dy[C], sum dy*xhat[C]} (fp64), i.e.
+ * d(beta) and d(gamma); the producer's backward turns dy into dz with them. */
+typedef struct YunetBN {
+    const double* stats;   /* [2*C] forward sums (zeroed before the step)            */
+    double* bstats;        /* [2*C] backward sums (zeroed before the step) or NULL    */
+    const float* gamma;    /* [C]                                                     */
+    const float* beta;     /* [C]                                                     */
+    int32_t count;         /* N*H*W of the normalised tensor                          */
+    float eps;
+} YunetBN;
+
+/* Input transform of a fused unit (how it reads its input tensor). */
+enum { YUNET_T_IDENTITY = 0, YUNET_T_BNRELU = 1 };
+
+/* One ConvDPUnit: 1x1 pointwise (bias) -> 3x3 depthwise (bias, zero-pads the pointwise
+ * output) [-> BN -> ReLU applied by the consumer].
+ * mmdet/models/utils/yunet_layer.py:4-36.  cin in {16,32,64}, cout in {16,32,64}. */
+typedef struct YunetDP {
+    int32_t N, H, W, cin, cout;
+    int32_t in_transform;      /* YUNET_T_*: applied to x on load                     */
+    int32_t out_has_bn;        /* 1: unit is followed by BN+ReLU (stats are produced) */
+    int32_t accumulate_dx;     /* bwd: dx += instead of dx =                          */
+    int64_t x_img_stride;      /* elements between images of x  (>= H*W*cin)          */
+    int64_t z_img_stride;      /* elements between images of z  (>= H*W*cout)         */
+    const float* x;            /* [N,H,W,cin] producer's raw output                   */
+    YunetBN in_bn;             /* BN of the producer (when in_transform == BNRELU)    */
+    const float* w_pw;         /* [cout,cin]                                          */
+    const float* b_pw;         /* [cout]                                              */
+    const float* w_dw;         /* [cout,9]                                            */
+    const float* b_dw;         /* [cout]                                              */
+    float* z;                  /* [N,H,W,cout] raw (pre-BN) output                    */
+    YunetBN out_bn;            /* this unit's BN (stats written fwd, bstats read bwd) */
+    /* backward only */
+    const float* dy;           /* [N,H,W,cout] grad wrt BN output (or wrt z if no BN) */
+    const float* dy_scale;     /* [cout] per-channel factor on dy (device) or NULL    */
+    float* dx;                 /* [N,H,W,cin] grad wrt the BN output of the producer
+                                  (ReLU mask applied) or wrt x if IDENTITY; NULL skips */
+    float* wgrad_partials;     /* [nblocks, cout*cin + cout + cout*9 + cout] fp32     */
+    int32_t wgrad_blocks;      /* number of partial rows (= launch grid)              */
+} YunetDP;
+
+/* ---- conv stack (mmdet/models/utils/yunet_layer.py, backbones/yunet_backbone.py:33-41,
+ *      necks/tfpn.py:33-45, dense_heads/yunet_head.py:175-247) ------------------- */
+
+/* Conv_head.conv1: 3x3 stride-2 conv 3->cmid (+bias), NCHW image in, NHWC raw out,
+ * BN statistics accumulated (yunet_layer.py:51-52,58). cmid must be 16. */
+int yunet_stem_fwd(const float* img, const float* w, const float* b, float* z,
+                   double* stats, int N, int H, int W, int cmid, void* stream);
+/* weight/bias gradient of the stem (no input gradient: the image is a leaf).
+ * dy is the grad wrt bn1's output with the ReLU mask applied; partials
+ * [blocks, cmid*27 + cmid] are reduced by yunet_reduce_partials. */
+int yunet_stem_bwd(const float* img, const float* z, const float* dy, const YunetBN* bn,
+                   float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
+                   void* stream);
+
+int yunet_dp_fwd(const YunetDP* d, void* stream);
+int yunet_dp_bwd(const YunetDP* d, void* stream);
+
+/* F.max_pool2d(relu(bn(z)), 2)  (yunet_backbone.py:39-40).  out [N,H/2,W/2,C]. */
+int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
+                   void* stream);
+/* dy_out [N,H/2,W/2,C] -> dz-side grad wrt bn output (mask applied) [N,H,W,C]; accumulates
+ * bn->bstats.  accumulate != 0: dx += . */
+int yunet_pool_bwd(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
+                   int accumulate, int N, int H, int W, int C, void* stream);
+
+/* TFPN merge: out = relu(bn_a(za)) + nearest_up2(relu(bn_b(zb)))  (tfpn.py:39-40).
+ * za [N,H,W,C], zb [N,H/2,W/2,C]. */
+int yunet_upadd_fwd(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
+                    float* out, int N, int H, int W, int C, void* stream);
+int yunet_upadd_bwd(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
+                    const float* dout, float* dxa, int accumulate_a, float* dxb,
+                    int accumulate_b, int N, int H, int W, int C, void* stream);
+
+/* BatchNorm running statistics: running = (1-m)*running + m*batch (unbiased var)
+ * for `count` BN layers described by parallel arrays (host pointers to device ptrs). */
+int yunet_bn_update_running(const double* stats, float* running_mean, float* running_var,
+                            int C, int count, float momentum, void* stream);
+
+/* Final BN parameter gradients: d(gamma) = bstats[C:2C], d(beta) = bstats[0:C]. */
+int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C,
+                        int accumulate, void* stream);
+
+/* out[j] (+)= sum_b partials[b, j]  for j < width, deterministic order. */
+int yunet_reduce_partials(const float* partials, int blocks, int width, float* out,
+                          int accumulate, void* stream);
+
+/* ---- loss step (mmdet/models/dense_heads/yunet_head.py:418-604) ---------------------- */
+
+#define YUNET_MAX_LEVELS 5
+typedef struct YunetLevels {
+    int32_t num_levels;
+    int32_t h[YUNET_MAX_LEVELS], w[YUNET_MAX_LEVELS], stride[YUNET_MAX_LEVELS];
+} YunetLevels;
+
+/* Fused MlvlPointGenerator priors (core/anchor/point_generator.py:80-175, offset 0) +
+ * _bbox_decode (yunet_head.py:376-386) + SimOTAAssigner._assign
+ * (core/bbox/assigners/sim_ota_assigner.py:95-257, bbox_overlaps
+ * core/bbox/iou_calculators/iou2d_calculator.py:232-253) + PseudoSampler, one image per
+ * workgroup.  flat [N,P,16] = cls | dx dy dw dh | obj | 10 kps.
+ * gt_boxes [N,Gmax,4] xyxy, gt_kps [N,Gmax,5,3] (x,y,vis), gt_labels [N,Gmax] or NULL,
+ * gt_count [N].  Outputs: gt_inds [N,P] int32 (1-based, 0 = background),
+ * labels [N,P] int32 (-1 background) or NULL, max_overlaps [N,P] (-1e5 background),
+ * img_stats [N,2] = {num_pos, sum of kps weights}.  scratch: [N,P,8] fp32.
+ * Ties at the k-th cost are broken towards the lowest prior index. */
+int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
+                 const int32_t* gt_labels, const int32_t* gt_count, const YunetLevels* lv,
+                 int N, int P, int Gmax, float center_radius, int32_t* gt_inds,
+                 int32_t* labels, float* max_overlaps, float* img_stats, float* scratch,
+                 void* stream);
+
+/* norm[0] = sum_n num_pos / world (the rank-local term of reduce_mean, yunet_head.py:493-497,
+ * to be all-reduced by the caller when world > 1), norm[1] = sum_n kps weight. */
+int yunet_loss_norm(const float* img_stats, int N, float inv_world, float* norm, void* stream);
+
+enum { YUNET_BOX_EIOU = 0, YUNET_BOX_DIOU = 1 };
+typedef struct YunetLossCfg {
+    int32_t box_loss;            /* YUNET_BOX_*  (losses/iou_loss.py:194-227 / 137-172) */
+    float w_cls, w_box, w_obj, w_kps;   /* loss_weight of each term                    */
+    float box_eps;               /* EIoULoss/DIoULoss eps (1e-6)                       */
+    float smooth_point;          /* EIoU 0.1                                           */
+    float kps_beta;              /* SmoothL1 beta (1/9)                                */
+} YunetLossCfg;
+
+/* The four YuNet_Head losses and d(loss_i)/d(flat) in one pass (yunet_head.py:506-532,
+ * losses/cross_entropy_loss.py:85-145, iou_loss.py, smooth_l1_loss.py:10-32,
+ * losses/utils.py:29-55).  norm[0] is the (all-reduced) mean num_pos, clamped to >= 1
+ * inside.  dflat [N,P,16] receives d(loss_c)/d(flat) for the loss that owns channel c,
+ * each with unit upstream gradient.  partials [blocks,4] -> losses via
+ * yunet_loss_finalize (losses = {cls, bbox, obj, kps}). */
+int yunet_loss(const float* flat, const int32_t* gt_inds, const float* max_overlaps,
+               const float* gt_boxes, const float* gt_kps, const YunetLevels* lv,
+               const YunetLossCfg* cfg, const float* norm, int N, int P, int Gmax,
+               float* dflat, float* partials, int blocks, void* stream);
+int yunet_loss_finalize(const float* partials, int blocks, float* losses, void* stream);
+int yunet_loss_blocks(int N, int P);
+
+/* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */
+/* g = grad*grad_scale + wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf.
+ * lr is read from device memory (lr_dev[0]) so schedules do not need a re-capture. */
+int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
+                   const float* lr_dev, float momentum, float weight_decay, float grad_scale,
+                   int first_step, void* stream);
+
+/* ---- op-list executor ---------------------------------------------------------------- */
+/* A training step is a fixed sequence of the calls above; the host builds it once as an
+ * array of YunetOp and replays it with one FFI call per phase. */
+enum {
+    YUNET_OP_STEM_FWD = 1, YUNET_OP_STEM_BWD, YUNET_OP_DP_FWD, YUNET_OP_DP_BWD,
+    YUNET_OP_POOL_FWD, YUNET_OP_POOL_BWD, YUNET_OP_UPADD_FWD, YUNET_OP_UPADD_BWD,
+    YUNET_OP_BN_RUNNING, YUNET_OP_BN_PARAM_GRAD, YUNET_OP_REDUCE_PARTIALS,
+    YUNET_OP_ASSIGN, YUNET_OP_LOSS_NORM, YUNET_OP_LOSS, YUNET_OP_LOSS_FINALIZE,
+    YUNET_OP_SGD, YUNET_OP_MEMSET
+};
+typedef struct YunetOp {
+    int32_t opcode;
+    int32_t i[12];
+    float f[8];
+    void* p[12];
+    YunetBN bn[2];
+    YunetDP dp;
+    YunetLevels lv;
+    YunetLossCfg loss;
+} YunetOp;
+int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
+
+int yunet_abi_version(void);
+/* grid size the fused conv kernels are launched with (rows of wgrad_partials). */
+int yunet_conv_blocks(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YUNET_HIP_H */

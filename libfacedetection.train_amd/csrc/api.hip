@@ -1,0 +1,122 @@
+// api.hip -- fused SGD, op-list executor and misc C-ABI entry points of libyunet_hip.so.
+#include "common.h"
+
+namespace {
+
+// torch.optim.SGD (momentum, weight_decay, dampening 0, no nesterov) over one flat buffer
+// (configs/yunet_n.py:1; weight decay hits every parameter, BN gamma/beta included).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, long long n,
+                                                  const float* __restrict__ lr_dev, float momentum,
+                                                  float wd, float gscale, int first) {
+    const float lr = lr_dev[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256) {
+        const float w = p[i];
+        const float d = g[i] * gscale + wd * w;
+        const float b = first ? d : buf[i] * momentum + d;
+        buf[i] = b;
+        p[i] = w - lr * b;
+    }
+}
+
+}  // namespace
+
+extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
+                              const float* lr_dev, float momentum, float weight_decay,
+                              float grad_scale, int first_step, void* stream) {
+    if (n < 1) return YUNET_EINVAL;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf, (long long)n, lr_dev, momentum, weight_decay, grad_scale,
+                       first_step);
+    return hip_status();
+}
+
+extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
+    for (int k = 0; k < n_ops; ++k) {
+        const YunetOp& o = ops[k];
+        int rc = 0;
+        switch (o.opcode) {
+            case YUNET_OP_STEM_FWD:
+                rc = yunet_stem_fwd((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                    (float*)o.p[3], (double*)o.p[4], o.i[0], o.i[1], o.i[2], o.i[3],
+                                    stream);
+                break;
+            case YUNET_OP_STEM_BWD:
+                rc = yunet_stem_bwd((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                    &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3],
+                                    stream);
+                break;
+            case YUNET_OP_DP_FWD:
+                rc = yunet_dp_fwd(&o.dp, stream);
+                break;
+            case YUNET_OP_DP_BWD:
+                rc = yunet_dp_bwd(&o.dp, stream);
+                break;
+            case YUNET_OP_POOL_FWD:
+                rc = yunet_pool_fwd((const float*)o.p[0], &o.bn[0], (float*)o.p[1], o.i[0], o.i[1],
+                                    o.i[2], o.i[3], stream);
+                break;
+            case YUNET_OP_POOL_BWD:
+                rc = yunet_pool_bwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1],
+                                    (float*)o.p[2], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case YUNET_OP_UPADD_FWD:
+                rc = yunet_upadd_fwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
+                                     (float*)o.p[2], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case YUNET_OP_UPADD_BWD:
+                rc = yunet_upadd_bwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
+                                     (const float*)o.p[2], (float*)o.p[3], o.i[4], (float*)o.p[4],
+                                     o.i[5], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case YUNET_OP_BN_RUNNING:
+                rc = yunet_bn_update_running((const double*)o.p[0], (float*)o.p[1], (float*)o.p[2],
+                                             o.i[0], o.i[1], o.f[0], stream);
+                break;
+            case YUNET_OP_BN_PARAM_GRAD:
+                rc = yunet_bn_param_grad((const double*)o.p[0], (float*)o.p[1], (float*)o.p[2], o.i[0],
+                                         o.i[1], stream);
+                break;
+            case YUNET_OP_REDUCE_PARTIALS:
+                rc = yunet_reduce_partials((const float*)o.p[0], o.i[0], o.i[1], (float*)o.p[1],
+                                           o.i[2], stream);
+                break;
+            case YUNET_OP_ASSIGN:
+                rc = yunet_assign((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                  (const int32_t*)o.p[3], (const int32_t*)o.p[4], &o.lv, o.i[0], o.i[1],
+                                  o.i[2], o.f[0], (int32_t*)o.p[5], (int32_t*)o.p[6], (float*)o.p[7],
+                                  (float*)o.p[8], (float*)o.p[9], stream);
+                break;
+            case YUNET_OP_LOSS_NORM:
+                rc = yunet_loss_norm((const float*)o.p[0], o.i[0], o.f[0], (float*)o.p[1], stream);
+                break;
+            case YUNET_OP_LOSS:
+                rc = yunet_loss((const float*)o.p[0], (const int32_t*)o.p[1], (const float*)o.p[2],
+                                (const float*)o.p[3], (const float*)o.p[4], &o.lv, &o.loss,
+                                (const float*)o.p[5], o.i[0], o.i[1], o.i[2], (float*)o.p[6],
+                                (float*)o.p[7], o.i[3], stream);
+                break;
+            case YUNET_OP_LOSS_FINALIZE:
+                rc = yunet_loss_finalize((const float*)o.p[0], o.i[0], (float*)o.p[1], stream);
+                break;
+            case YUNET_OP_SGD: {
+                const int64_t n = ((int64_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
+                rc = yunet_sgd_step((float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], n,
+                                    (const float*)o.p[3], o.f[0], o.f[1], o.f[2], o.i[2], stream);
+                break;
+            }
+            case YUNET_OP_MEMSET: {
+                const size_t n = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
+                rc = -(int)hipMemsetAsync(o.p[0], 0, n, (hipStream_t)stream);
+                break;
+            }
+            default:
+                return YUNET_EOPCODE;
+        }
+        if (rc != 0) return rc < 0 ? rc * 1000 - k : -(rc * 1000 + k);
+    }
+    return 0;
+}

@@ -1,0 +1,63 @@
+// common.h -- shared device helpers for the YuNet gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yunet_hip.h"
+
+// Every conv-stack kernel is launched as a persistent grid of CONV_BLOCKS workgroups that
+// stride over tiles; per-workgroup partial sums (BN statistics, weight gradients) are
+// flushed once at the end, which bounds the number of same-address atomics / partial rows.
+#define CONV_BLOCKS 1024
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(16x4) * B(4x16) + C, exact fp32 (v_mfma_f32_16x16x4_f32).
+// lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
+// D/C: col = l&15, row = (l>>4)*4 + reg.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Per-channel constants of a train-mode BatchNorm, derived from the producer's fp64 sums.
+//   y = (x - mean) * scale + beta,  scale = gamma * invstd,  invstd = 1/sqrt(var_biased + eps)
+struct BNCoef {
+    float mean, scale, beta, invstd;
+};
+__device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
+    const double inv = 1.0 / (double)bn.count;
+    const double mean = bn.stats[c] * inv;
+    double var = bn.stats[C + c] * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    BNCoef k;
+    k.mean = (float)mean;
+    k.invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
+    k.scale = bn.gamma[c] * k.invstd;
+    k.beta = bn.beta[c];
+    return k;
+}
+// backward constants: dz = k1 * (dy - c1 - xhat * c2), xhat = (z - mean) * invstd
+struct BNBwd {
+    float mean, invstd, k1, c1, c2;
+};
+__device__ __forceinline__ BNBwd bn_bwd_coef(const YunetBN& bn, int C, int c) {
+    const BNCoef f = bn_coef(bn, C, c);
+    const double inv = 1.0 / (double)bn.count;
+    BNBwd k;
+    k.mean = f.mean;
+    k.invstd = f.invstd;
+    k.k1 = f.scale;
+    k.c1 = (float)(bn.bstats[c] * inv);
+    k.c2 = (float)(bn.bstats[C + c] * inv);
+    return k;
+}
+
+__device__ __forceinline__ float bnrelu(float x, float mean, float scale, float beta) {
+    return fmaxf(fmaf(x - mean, scale, beta), 0.0f);
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static inline int hip_status() { return -(int)hipGetLastError(); }

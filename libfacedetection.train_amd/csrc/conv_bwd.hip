@@ -1,0 +1,780 @@
+// conv_bwd.hip -- backward kernels of the YuNet conv stack on gfx950 (NHWC fp32).
+//
+// The reference gets these from autograd over F.conv2d / batch_norm / relu / max_pool2d /
+// interpolate.  Gradient tensors exchanged between kernels are
+// "grad w.r.t. the BatchNorm OUTPUT with the ReLU mask applied" (dy); the kernel that
+// produces dy also accumulates the two BN-backward sums (sum dy, sum dy*xhat) in fp64, and
+// the producer's backward turns dy into dz = k1*(dy - c1 - xhat*c2) while loading.
+//
+// dp_bwd per 8x16 tile (512 threads): dz halo -> LDS; a = T(x) -> LDS; p = a*W1^T+b1 (MFMA,
+// recomputed, never stored in HBM); depthwise backward on the VALU (dp, dW2, db2, db1);
+// dW1 += a^T * dp (MFMA, K = pixels, accumulators persistent across tiles);
+// da = dp * W1 (MFMA); dx = da * relu-mask, BN-backward sums of the producer.
+#include "common.h"
+
+namespace {
+
+#define BWD_THREADS 512
+#define BWD_WAVES 8
+
+template <int CIN, int COUT, int TH, int TW>
+struct BwdGeom {
+    static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_;
+    static constexpr int IP = TH * TW, IMT = IP / 16;
+    static constexpr int LSO = COUT + 4, LSI = CIN + 4, WS = CIN + 2;
+    static constexpr int C4I = CIN / 4, C4O = COUT / 4;
+    static constexpr int NTO = COUT / 16, NTI = CIN / 16;
+    static constexpr int KSI = CIN / 4, KSO = COUT / 4;
+    static constexpr int PG = BWD_THREADS / C4O;   // pixel groups of the VALU phase
+    static constexpr int PPT = IP / PG;            // pixels (rows) per thread
+    static constexpr int NTILE = NTI * NTO;        // 16x16 tiles of dW1
+    static constexpr int TPW = NTILE >= BWD_WAVES ? NTILE / BWD_WAVES : 1;
+    static constexpr int KSPLIT = NTILE >= BWD_WAVES ? 1 : BWD_WAVES / NTILE;
+    static constexpr int KSTEPS = (IP / 4) / KSPLIT;  // k-steps of 4 pixels per wave
+    // LDS carve (floats)
+    static constexpr int OFF_DZ = 0;
+    static constexpr int OFF_A = OFF_DZ + HP * LSO;
+    static constexpr int OFF_PB = OFF_A + IP * LSI;
+    static constexpr int OFF_W1 = OFF_PB + IP * LSO;
+    static constexpr int OFF_CO = OFF_W1 + COUT * WS;   // out-bn bwd coefs 5*COUT
+    static constexpr int OFF_CI = OFF_CO + 5 * COUT;    // in-bn coefs 4*CIN
+    static constexpr int TOTAL = OFF_CI + 4 * CIN;
+    static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
+    static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
+    static constexpr size_t RED2 = (size_t)BWD_THREADS * 8 * 8;       // bstats reduction
+    static constexpr size_t WORK = (size_t)OFF_W1 * 4;
+    static constexpr size_t WORKB = WORK > RED1 ? (WORK > RED2 ? WORK : RED2) : (RED1 > RED2 ? RED1 : RED2);
+    static constexpr size_t SMEM = WORKB + (size_t)(TOTAL - OFF_W1) * 4;
+    static_assert(IP % 16 == 0 && IMT == BWD_WAVES, "one 16-pixel M tile per wave");
+    static_assert(PG % TW == 0 && IP % PG == 0, "VALU mapping");
+    static_assert(BWD_THREADS % C4I == 0 && BWD_THREADS % C4O == 0, "load mapping");
+    static_assert((IP / 4) % KSPLIT == 0, "k split");
+};
+
+template <int CIN, int COUT, int TH, int TW>
+__global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
+    using G = BwdGeom<CIN, COUT, TH, TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);
+    float* s_dz = sm + G::OFF_DZ;
+    float* s_a = sm + G::OFF_A;
+    float* s_pb = sm + G::OFF_PB;
+    // the parameter/coefficient block sits after the (possibly larger) reduction work area
+    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);
+    float* s_co = s_w1 + COUT * G::WS;
+    float* s_ci = s_co + 5 * COUT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int H = d.H, W = d.W;
+    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
+    const bool bn_out = d.out_has_bn != 0;
+
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
+        const int co = i / CIN, ci = i - co * CIN;
+        s_w1[co * G::WS + ci] = d.w_pw[i];
+    }
+    for (int c = tid; c < COUT; c += BWD_THREADS) {
+        if (bn_out) {
+            const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
+            s_co[c] = k.mean; s_co[COUT + c] = k.invstd; s_co[2 * COUT + c] = k.k1;
+            s_co[3 * COUT + c] = k.c1; s_co[4 * COUT + c] = k.c2;
+        } else {
+            s_co[c] = 0.f; s_co[COUT + c] = 0.f;
+            s_co[2 * COUT + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
+            s_co[3 * COUT + c] = 0.f; s_co[4 * COUT + c] = 0.f;
+        }
+    }
+    for (int c = tid; c < CIN; c += BWD_THREADS) {
+        if (bn_in) {
+            const BNCoef k = bn_coef(d.in_bn, CIN, c);
+            s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
+            s_ci[3 * CIN + c] = k.invstd;
+        } else {
+            s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f; s_ci[3 * CIN + c] = 1.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-thread constants ---------------------------------------------------------------
+    const int och4 = tid % G::C4O;   // output-channel quad in the dz load phase
+    const int ich4 = tid % G::C4I;   // input-channel quad in the a load / final phases
+    // (the per-channel BN constants stay in LDS and are re-read per phase: keeping them
+    //  live across the MFMA phases costs ~36 VGPRs and pushes the kernel into spills)
+    float bias_pw[G::NTO];
+#pragma unroll
+    for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = d.b_pw[nt * 16 + l15];
+    // VALU phase: channel quad cq, pixel column vtx, rows vr0..vr0+PPT-1
+    const int cq = tid % G::C4O, pg = tid / G::C4O;
+    const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
+    float4 w2[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        w2[t] = make_float4(d.w_dw[(cq * 4 + 0) * 9 + t], d.w_dw[(cq * 4 + 1) * 9 + t],
+                            d.w_dw[(cq * 4 + 2) * 9 + t], d.w_dw[(cq * 4 + 3) * 9 + t]);
+    float4 gw2[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gw2[t] = make_float4(0, 0, 0, 0);
+    float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
+    double bst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bst[i] = 0.0;
+    // dW1 accumulators: this wave's 16x16 tiles (m = ci block, n = co block)
+    f32x4 gw1[G::TPW];
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w1_tile0 = G::KSPLIT == 1 ? wid * G::TPW : wid % G::NTILE;
+    const int w1_kslice = G::KSPLIT == 1 ? 0 : wid / G::NTILE;
+
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = d.N * tiles_x * tiles_y;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y);
+        const int rr = t - n * tiles_x * tiles_y;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const float* xin = d.x + (size_t)n * d.x_img_stride;
+        const float* zo = d.z + (size_t)n * d.z_img_stride;
+        const float* dyo = d.dy + (size_t)n * d.z_img_stride;
+
+        // ---- phase 1: dz halo tile and transformed input tile -> LDS ---------------------------
+        {
+        const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
+        const float4 o_inv = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
+        const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
+        const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
+        const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
+        for (int q = tid; q < G::HP * G::C4O; q += BWD_THREADS) {
+            const int hp = q / G::C4O;
+            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const size_t off = ((size_t)y * W + x) * COUT + och4 * 4;
+                const float4 dy = *reinterpret_cast<const float4*>(dyo + off);
+                if (bn_out) {
+                    const float4 z = *reinterpret_cast<const float4*>(zo + off);
+                    v.x = o_k1.x * (dy.x - o_c1.x - (z.x - o_mean.x) * o_inv.x * o_c2.x);
+                    v.y = o_k1.y * (dy.y - o_c1.y - (z.y - o_mean.y) * o_inv.y * o_c2.y);
+                    v.z = o_k1.z * (dy.z - o_c1.z - (z.z - o_mean.z) * o_inv.z * o_c2.z);
+                    v.w = o_k1.w * (dy.w - o_c1.w - (z.w - o_mean.w) * o_inv.w * o_c2.w);
+                } else {
+                    v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
+                }
+            }
+            *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
+        }
+        }
+        {
+        const float4 i_mean = *reinterpret_cast<float4*>(s_ci + ich4 * 4);
+        const float4 i_scale = *reinterpret_cast<float4*>(s_ci + CIN + ich4 * 4);
+        const float4 i_beta = *reinterpret_cast<float4*>(s_ci + 2 * CIN + ich4 * 4);
+        for (int q = tid; q < G::IP * G::C4I; q += BWD_THREADS) {
+            const int ip = q / G::C4I;
+            const int y = y0 + ip / TW, x = x0 + ip % TW;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (y < H && x < W) {
+                v = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN + ich4 * 4);
+                if (bn_in) {
+                    v.x = bnrelu(v.x, i_mean.x, i_scale.x, i_beta.x);
+                    v.y = bnrelu(v.y, i_mean.y, i_scale.y, i_beta.y);
+                    v.z = bnrelu(v.z, i_mean.z, i_scale.z, i_beta.z);
+                    v.w = bnrelu(v.w, i_mean.w, i_scale.w, i_beta.w);
+                }
+            }
+            *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = v;
+        }
+        }
+        __syncthreads();
+
+        // ---- phase 2: p = a * W1^T + b1 on the interior pixels (one M tile per wave) -----------
+        {
+            f32x4 acc[G::NTO];
+#pragma unroll
+            for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* arow = s_a + (wid * 16 + l15) * G::LSI + g;
+#pragma unroll
+            for (int s = 0; s < G::KSI; ++s) {
+                const float a = arow[4 * s];
+#pragma unroll
+                for (int nt = 0; nt < G::NTO; ++nt)
+                    acc[nt] = mfma16(a, s_w1[(nt * 16 + l15) * G::WS + 4 * s + g], acc[nt]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ip = wid * 16 + 4 * g + r;
+                const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+#pragma unroll
+                for (int nt = 0; nt < G::NTO; ++nt)
+                    s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: depthwise backward on the VALU; dp overwrites p in place ------------------
+#pragma unroll
+        for (int r = 0; r < G::PPT; ++r) {
+            const int ty = vr0 + r;
+            const bool in = (y0 + ty) < H && (x0 + vtx) < W;
+            float* pp = s_pb + (ty * TW + vtx) * G::LSO + cq * 4;
+            const float4 p = *reinterpret_cast<const float4*>(pp);
+            float4 dp = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float4 z4 = *reinterpret_cast<const float4*>(
+                        s_dz + ((ty + a) * G::HW_ + vtx + b) * G::LSO + cq * 4);
+                    const int k = 8 - (3 * a + b);
+                    dp.x = fmaf(z4.x, w2[k].x, dp.x); dp.y = fmaf(z4.y, w2[k].y, dp.y);
+                    dp.z = fmaf(z4.z, w2[k].z, dp.z); dp.w = fmaf(z4.w, w2[k].w, dp.w);
+                    gw2[k].x = fmaf(p.x, z4.x, gw2[k].x); gw2[k].y = fmaf(p.y, z4.y, gw2[k].y);
+                    gw2[k].z = fmaf(p.z, z4.z, gw2[k].z); gw2[k].w = fmaf(p.w, z4.w, gw2[k].w);
+                    if (a == 1 && b == 1) {
+                        gb2.x += z4.x; gb2.y += z4.y; gb2.z += z4.z; gb2.w += z4.w;
+                    }
+                }
+            if (!in) dp = make_float4(0, 0, 0, 0);
+            gb1.x += dp.x; gb1.y += dp.y; gb1.z += dp.z; gb1.w += dp.w;
+            *reinterpret_cast<float4*>(pp) = dp;
+        }
+        __syncthreads();
+
+        // ---- phase 4: dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores --------
+#pragma unroll
+        for (int i = 0; i < G::TPW; ++i) {
+            const int tile = w1_tile0 + i;
+            const int mt = tile / G::NTO, nt = tile - mt * G::NTO;  // ci block, co block
+            const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + mt * 16 + l15;
+            const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + nt * 16 + l15;
+#pragma unroll 8
+            for (int s = 0; s < G::KSTEPS; ++s)
+                gw1[i] = mfma16(ap[4 * s * G::LSI], bp[4 * s * G::LSO], gw1[i]);
+        }
+        f32x4 da[G::NTI];
+#pragma unroll
+        for (int nt = 0; nt < G::NTI; ++nt) da[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* prow = s_pb + (wid * 16 + l15) * G::LSO + g;
+#pragma unroll
+            for (int s = 0; s < G::KSO; ++s) {
+                const float a = prow[4 * s];
+#pragma unroll
+                for (int nt = 0; nt < G::NTI; ++nt)
+                    da[nt] = mfma16(a, s_w1[(4 * s + g) * G::WS + nt * 16 + l15], da[nt]);
+            }
+        }
+        __syncthreads();  // every wave is done reading s_a for dW1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ip = wid * 16 + 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < G::NTI; ++nt) {
+                float* ap = s_a + ip * G::LSI + nt * 16 + l15;
+                const float v = da[nt][r];
+                *ap = bn_in ? (*ap > 0.0f ? v : 0.0f) : v;   // ReLU mask of the input transform
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 5: dx store (coalesced) + BN-backward sums of the producer --------------------
+        if (d.dx) {
+            const float4 i_mean = *reinterpret_cast<float4*>(s_ci + ich4 * 4);
+            const float4 i_inv = *reinterpret_cast<float4*>(s_ci + 3 * CIN + ich4 * 4);
+            float* dxo = d.dx + (size_t)n * d.x_img_stride;
+            for (int q = tid; q < G::IP * G::C4I; q += BWD_THREADS) {
+                const int ip = q / G::C4I;
+                const int y = y0 + ip / TW, x = x0 + ip % TW;
+                if (y < H && x < W) {
+                    const size_t off = ((size_t)y * W + x) * CIN + ich4 * 4;
+                    float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
+                    if (bn_in) {
+                        const float4 xr = *reinterpret_cast<const float4*>(xin + off);
+                        bst[0] += (double)v.x; bst[1] += (double)v.y;
+                        bst[2] += (double)v.z; bst[3] += (double)v.w;
+                        bst[4] += (double)(v.x * ((xr.x - i_mean.x) * i_inv.x));
+                        bst[5] += (double)(v.y * ((xr.y - i_mean.y) * i_inv.y));
+                        bst[6] += (double)(v.z * ((xr.z - i_mean.z) * i_inv.z));
+                        bst[7] += (double)(v.w * ((xr.w - i_mean.w) * i_inv.w));
+                    }
+                    float4* dst = reinterpret_cast<float4*>(dxo + off);
+                    if (d.accumulate_dx) {
+                        const float4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *dst = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ============ flush per-workgroup partial sums ==============================================
+    float* row = d.wgrad_partials + (size_t)blockIdx.x * G::WROW;
+    // (a) dW1: MFMA accumulators -> LDS [COUT][CIN] (summing the K slices in a fixed order)
+    float* s_gw1 = sm;  // COUT*CIN floats, fits in the work area
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) s_gw1[i] = 0.0f;
+    __syncthreads();
+    for (int ks = 0; ks < G::KSPLIT; ++ks) {
+        if (w1_kslice == ks) {
+#pragma unroll
+            for (int i = 0; i < G::TPW; ++i) {
+                const int tile = w1_tile0 + i;
+                const int mt = tile / G::NTO, nt = tile - mt * G::NTO;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_gw1[(nt * 16 + l15) * CIN + mt * 16 + 4 * g + r] += gw1[i][r];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) row[i] = s_gw1[i];
+    __syncthreads();
+    // (b) db1 | dW2 | db2: reduce the per-thread accumulators over the pixel groups, in three
+    //     passes of <= 16 floats per thread (keeps the LDS footprint at 32 KB)
+    {
+        float* red = sm;  // [BWD_THREADS][16]
+        float* my = red + tid * 16;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            // slots of this pass: taps 4*pass .. 4*pass+3 (pass 2: tap 8, db1, db2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = make_float4(0, 0, 0, 0);
+                if (pass < 2) v = gw2[pass * 4 + j];
+                else if (j == 0) v = gw2[8];
+                else if (j == 1) v = gb1;
+                else if (j == 2) v = gb2;
+                my[j * 4 + 0] = v.x; my[j * 4 + 1] = v.y; my[j * 4 + 2] = v.z; my[j * 4 + 3] = v.w;
+            }
+            __syncthreads();
+            const int nslot = pass < 2 ? 4 : 3;
+            for (int o = tid; o < COUT * nslot; o += BWD_THREADS) {
+                const int c = o / nslot, j = o - c * nslot;
+                const int q = c >> 2, e = c & 3;
+                float v = 0.0f;
+                for (int p = 0; p < G::PG; ++p) v += red[(p * G::C4O + q) * 16 + j * 4 + e];
+                if (pass < 2) row[COUT * CIN + COUT + c * 9 + pass * 4 + j] = v;
+                else if (j == 0) row[COUT * CIN + COUT + c * 9 + 8] = v;
+                else if (j == 1) row[COUT * CIN + c] = v;
+                else row[COUT * CIN + COUT + COUT * 9 + c] = v;
+            }
+            __syncthreads();
+        }
+    }
+    // (c) BN-backward sums of the producer: fp64 block reduce, one atomic per channel
+    if (bn_in && d.dx && d.in_bn.bstats) {
+        double* red = reinterpret_cast<double*>(smem_raw);  // [BWD_THREADS][8]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = bst[i];
+        __syncthreads();
+        if (tid < 2 * CIN) {
+            const int which = tid / CIN, c = tid % CIN;
+            const int q = c >> 2, k = (c & 3) + 4 * which;
+            double v = 0.0;
+            for (int p = 0; p < BWD_THREADS / G::C4I; ++p) v += red[(p * G::C4I + q) * 8 + k];
+            atomic_add_f64(d.in_bn.bstats + which * CIN + c, v);
+        }
+    }
+}
+
+template <int CIN, int COUT, int TH, int TW>
+int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
+    using G = BwdGeom<CIN, COUT, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+        attr_set = true;
+    }
+    const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
+    int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
+    if (grid < 1) return YUNET_EINVAL;
+    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
+                       stream, *d);
+    return hip_status();
+}
+
+// ----------------------------------------------------------------------------- stem wgrad
+#define SB_TW 32
+#define SB_TH 8
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img,
+                                                       const float* __restrict__ z,
+                                                       const float* __restrict__ dy, YunetBN bn,
+                                                       float* __restrict__ partials, int N, int H,
+                                                       int W) {
+    constexpr int PH = 2 * SB_TH + 1, PW = 2 * SB_TW + 1, PWS = PW + 1;
+    constexpr int DZS = 20;
+    constexpr int PATCH_F = ((3 * PH * PWS + 3) / 4) * 4;
+    constexpr int DZT_F = SB_TH * SB_TW * DZS;
+    constexpr int ALL_F = (PATCH_F + DZT_F) > 256 * 33 ? (PATCH_F + DZT_F) : 256 * 33;
+    __shared__ __attribute__((aligned(16))) float s_all[ALL_F];
+    float* s_patch = s_all;
+    float* s_dzt = s_all + PATCH_F;
+    __shared__ float s_k[5][16];
+    const int tid = threadIdx.x;
+    const int Ho = H / 2, Wo = W / 2;
+    if (tid < 16) {
+        const BNBwd k = bn_bwd_coef(bn, 16, tid);
+        s_k[0][tid] = k.mean; s_k[1][tid] = k.invstd; s_k[2][tid] = k.k1;
+        s_k[3][tid] = k.c1; s_k[4][tid] = k.c2;
+    }
+    __syncthreads();
+    const int lc4 = tid & 3;  // channel quad in the dz load phase
+    float km[4], ki[4], k1[4], c1[4], c2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        km[i] = s_k[0][lc4 * 4 + i]; ki[i] = s_k[1][lc4 * 4 + i]; k1[i] = s_k[2][lc4 * 4 + i];
+        c1[i] = s_k[3][lc4 * 4 + i]; c2[i] = s_k[4][lc4 * 4 + i];
+    }
+    // role: 4 output-channel quads x 4 tap groups of 7; 16 pixel slices of 16 pixels
+    const int role = tid & 15, slice = tid >> 4;
+    const int cog = role & 3, tg = role >> 2;
+    int toff[7];
+    bool tok[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int t = tg * 7 + k;
+        tok[k] = t < 27;
+        const int tt = tok[k] ? t : 0;
+        const int ci = tt / 9, ky = (tt % 9) / 3, kx = tt % 3;
+        toff[k] = ci * PH * PWS + ky * PWS + kx;
+    }
+    float4 acc[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = make_float4(0, 0, 0, 0);
+    float4 accb = make_float4(0, 0, 0, 0);
+
+    const int tiles_x = (Wo + SB_TW - 1) / SB_TW, tiles_y = (Ho + SB_TH - 1) / SB_TH;
+    const int ntiles = N * tiles_x * tiles_y;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y);
+        const int r = t - n * tiles_x * tiles_y;
+        const int y0 = (r / tiles_x) * SB_TH, x0 = (r % tiles_x) * SB_TW;
+        __syncthreads();
+        for (int i = tid; i < 3 * PH * PW; i += 256) {
+            const int ci = i / (PH * PW), q = i - ci * PH * PW;
+            const int py = q / PW, px = q - py * PW;
+            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+            float v = 0.0f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = img[(((size_t)n * 3 + ci) * H + iy) * W + ix];
+            s_patch[ci * PH * PWS + py * PWS + px] = v;
+        }
+        for (int q = tid; q < SB_TH * SB_TW * 4; q += 256) {
+            const int pix = q >> 2;
+            const int oy = y0 + pix / SB_TW, ox = x0 + pix % SB_TW;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (oy < Ho && ox < Wo) {
+                const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * 16 + lc4 * 4;
+                const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
+                const float4 z4 = *reinterpret_cast<const float4*>(z + off);
+                v.x = k1[0] * (g4.x - c1[0] - (z4.x - km[0]) * ki[0] * c2[0]);
+                v.y = k1[1] * (g4.y - c1[1] - (z4.y - km[1]) * ki[1] * c2[1]);
+                v.z = k1[2] * (g4.z - c1[2] - (z4.z - km[2]) * ki[2] * c2[2]);
+                v.w = k1[3] * (g4.w - c1[3] - (z4.w - km[3]) * ki[3] * c2[3]);
+            }
+            *reinterpret_cast<float4*>(s_dzt + pix * DZS + lc4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int pix = slice * 16 + j;
+            const int ty = pix / SB_TW, tx = pix % SB_TW;
+            const float4 dz = *reinterpret_cast<const float4*>(s_dzt + pix * DZS + cog * 4);
+            const float* pb = s_patch + 2 * ty * PWS + 2 * tx;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const float v = tok[k] ? pb[toff[k]] : 0.0f;
+                acc[k].x = fmaf(v, dz.x, acc[k].x); acc[k].y = fmaf(v, dz.y, acc[k].y);
+                acc[k].z = fmaf(v, dz.z, acc[k].z); acc[k].w = fmaf(v, dz.w, acc[k].w);
+            }
+            if (tg == 0) { accb.x += dz.x; accb.y += dz.y; accb.z += dz.z; accb.w += dz.w; }
+        }
+    }
+    // reduce over the 16 pixel slices
+    __syncthreads();
+    float* red = s_all;  // [256][33], aliases the patch / dz tiles (all reads are done)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        red[tid * 33 + k * 4 + 0] = acc[k].x; red[tid * 33 + k * 4 + 1] = acc[k].y;
+        red[tid * 33 + k * 4 + 2] = acc[k].z; red[tid * 33 + k * 4 + 3] = acc[k].w;
+    }
+    red[tid * 33 + 28] = accb.x; red[tid * 33 + 29] = accb.y;
+    red[tid * 33 + 30] = accb.z; red[tid * 33 + 31] = accb.w;
+    __syncthreads();
+    float* row = partials + (size_t)blockIdx.x * (16 * 27 + 16);
+    for (int o = tid; o < 16 * 27 + 16; o += 256) {
+        float v = 0.0f;
+        if (o < 16 * 27) {
+            const int co = o / 27, tt = o - co * 27;
+            const int tgi = tt / 7, k = tt - tgi * 7;
+            const int rl = tgi * 4 + (co >> 2);
+            for (int s = 0; s < 16; ++s) v += red[(s * 16 + rl) * 33 + k * 4 + (co & 3)];
+        } else {
+            const int co = o - 16 * 27;
+            const int rl = (co >> 2);  // tg == 0
+            for (int s = 0; s < 16; ++s) v += red[(s * 16 + rl) * 33 + 28 + (co & 3)];
+        }
+        row[o] = v;
+    }
+}
+
+// ------------------------------------------------------------------- pool / upsample-add
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ z, YunetBN bn,
+                                                       const float* __restrict__ dyo,
+                                                       float* __restrict__ dx, int accumulate, int N,
+                                                       int H, int W, int C) {
+    const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    const int c4 = threadIdx.x % C4;
+    BNCoef k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = bn_coef(bn, C, c4 * 4 + i);
+    double bst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bst[i] = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        long long pix = e / C4;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
+        const float4 g4 = *reinterpret_cast<const float4*>(dyo + e * 4);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float zv[4][4], yv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(
+                z + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
+            zv[j][0] = v.x; zv[j][1] = v.y; zv[j][2] = v.z; zv[j][3] = v.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yv[j][i] = bnrelu(zv[j][i], k[i].mean, k[i].scale, k[i].beta);
+        }
+        float o[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int am = 0;
+            float m = yv[0][i];
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (yv[j][i] > m) { m = yv[j][i]; am = j; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j][i] = (j == am && m > 0.0f) ? gv[i] : 0.0f;
+            if (m > 0.0f) {
+                bst[i] += (double)gv[i];
+                bst[4 + i] += (double)(gv[i] * ((zv[am][i] - k[i].mean) * k[i].invstd));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4* dst = reinterpret_cast<float4*>(
+                dx + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
+            float4 v = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            if (accumulate) {
+                const float4 p = *dst;
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *dst = v;
+        }
+    }
+    __shared__ double red[256 * 8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = bst[i];
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C && bn.bstats) {
+        const int which = threadIdx.x / C, c = threadIdx.x % C;
+        const int q = c >> 2, kk = (c & 3) + 4 * which;
+        double v = 0.0;
+        for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];
+        atomic_add_f64(bn.bstats + which * C + c, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict__ za, YunetBN bna,
+                                                        const float* __restrict__ zb, YunetBN bnb,
+                                                        const float* __restrict__ dout,
+                                                        float* __restrict__ dxa, int acc_a,
+                                                        float* __restrict__ dxb, int acc_b, int N,
+                                                        int H, int W, int C) {
+    // one thread = one float4 of one COARSE pixel (covers the 2x2 fine pixels)
+    const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
+    const long long total = (long long)N * Hb * Wb * C4;
+    const int c4 = threadIdx.x % C4;
+    BNCoef ka[4], kb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ka[i] = bn_coef(bna, C, c4 * 4 + i);
+        kb[i] = bn_coef(bnb, C, c4 * 4 + i);
+    }
+    double bsa[8], bsb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsa[i] = bsb[i] = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        long long pix = e / C4;
+        const int bx = (int)(pix % Wb);
+        pix /= Wb;
+        const int by = (int)(pix % Hb), n = (int)(pix / Hb);
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t off = (((size_t)n * H + 2 * by + (j >> 1)) * W + 2 * bx + (j & 1)) * C + c4 * 4;
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + off);
+            const float4 z4 = *reinterpret_cast<const float4*>(za + off);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sum[i] += gv[i];
+                const bool on = bnrelu(zv[i], ka[i].mean, ka[i].scale, ka[i].beta) > 0.0f;
+                o[i] = on ? gv[i] : 0.0f;
+                if (on) {
+                    bsa[i] += (double)gv[i];
+                    bsa[4 + i] += (double)(gv[i] * ((zv[i] - ka[i].mean) * ka[i].invstd));
+                }
+            }
+            float4* dst = reinterpret_cast<float4*>(dxa + off);
+            float4 v = make_float4(o[0], o[1], o[2], o[3]);
+            if (acc_a) {
+                const float4 p = *dst;
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *dst = v;
+        }
+        const size_t offb = (((size_t)n * Hb + by) * Wb + bx) * C + c4 * 4;
+        const float4 zb4 = *reinterpret_cast<const float4*>(zb + offb);
+        const float zbv[4] = {zb4.x, zb4.y, zb4.z, zb4.w};
+        float ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = bnrelu(zbv[i], kb[i].mean, kb[i].scale, kb[i].beta) > 0.0f;
+            ob[i] = on ? sum[i] : 0.0f;
+            if (on) {
+                bsb[i] += (double)sum[i];
+                bsb[4 + i] += (double)(sum[i] * ((zbv[i] - kb[i].mean) * kb[i].invstd));
+            }
+        }
+        float4* dstb = reinterpret_cast<float4*>(dxb + offb);
+        float4 v = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        if (acc_b) {
+            const float4 p = *dstb;
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *dstb = v;
+    }
+    __shared__ double red[256 * 8];
+#define UPADD_FLUSH(SRC, DST)                                                        \
+    __syncthreads();                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = SRC[i]; \
+    __syncthreads();                                                                 \
+    if ((int)threadIdx.x < 2 * C && DST) {                                           \
+        const int which = threadIdx.x / C, c = threadIdx.x % C;                      \
+        const int q = c >> 2, kk = (c & 3) + 4 * which;                              \
+        double v = 0.0;                                                              \
+        for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];          \
+        atomic_add_f64(DST + which * C + c, v);                                      \
+    }
+    UPADD_FLUSH(bsa, bna.bstats)
+    UPADD_FLUSH(bsb, bnb.bstats)
+#undef UPADD_FLUSH
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ bstats, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float db = (float)bstats[c], dg = (float)bstats[C + c];
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+}
+
+// out[j] (+)= sum_b partials[b][j]: one thread per column, fixed order, coalesced rows
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials,
+                                                              int blocks, int width,
+                                                              float* __restrict__ out,
+                                                              int accumulate) {
+    // 4 row-slices per block (64 columns x 4 slices), then a fixed-order combine
+    __shared__ float s[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
+    float v = 0.0f;
+    if (col < width)
+        for (int b = sl; b < blocks; b += 4) v += partials[(size_t)b * width + col];
+    s[sl][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (sl == 0 && col < width) {
+        const float t = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
+inline int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!d->wgrad_partials || d->wgrad_blocks < 1) return YUNET_EINVAL;
+#define DP_CASE(ci, co) \
+    if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
+    DP_CASE(16, 16)
+    DP_CASE(16, 32)
+    DP_CASE(16, 64)
+    DP_CASE(32, 32)
+    DP_CASE(32, 64)
+    DP_CASE(64, 64)
+    DP_CASE(64, 16)
+#undef DP_CASE
+    return YUNET_EINVAL;
+}
+
+extern "C" int yunet_stem_bwd(const float* img, const float* z, const float* dy, const YunetBN* bn,
+                              float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
+                              void* stream) {
+    if (cmid != 16 || (H & 1) || (W & 1) || wgrad_blocks < 1) return YUNET_EINVAL;
+    const int tiles = N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
+    int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    if (grid > wgrad_blocks) grid = wgrad_blocks;
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, z, dy, *bn,
+                       wgrad_partials, N, H, W);
+    return hip_status();
+}
+
+extern "C" int yunet_pool_bwd(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
+                              int accumulate, int N, int H, int W, int C, void* stream) {
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z, *bn,
+                       dy_out, dx, accumulate, N, H, W, C);
+    return hip_status();
+}
+
+extern "C" int yunet_upadd_bwd(const float* za, const YunetBN* bna, const float* zb,
+                               const YunetBN* bnb, const float* dout, float* dxa, int accumulate_a,
+                               float* dxb, int accumulate_b, int N, int H, int W, int C,
+                               void* stream) {
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, za,
+                       *bna, zb, *bnb, dout, dxa, accumulate_a, dxb, accumulate_b, N, H, W, C);
+    return hip_status();
+}
+
+extern "C" int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C,
+                                   int accumulate, void* stream) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       bstats, dgamma, dbeta, C, accumulate);
+    return hip_status();
+}
+
+extern "C" int yunet_reduce_partials(const float* partials, int blocks, int width, float* out,
+                                     int accumulate, void* stream) {
+    if (blocks < 1 || width < 1) return YUNET_EINVAL;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, partials, blocks, width, out, accumulate);
+    return hip_status();
+}

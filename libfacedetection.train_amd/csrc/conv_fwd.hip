@@ -1,0 +1,455 @@
+// conv_fwd.hip -- forward kernels of the YuNet conv stack on gfx950 (NHWC fp32).
+//
+//   stem_fwd   Conv_head.conv1: 3x3 stride-2 3->16 (+bias)     yunet_layer.py:51-52,58
+//   dp_fwd     ConvDPUnit: 1x1 pointwise (MFMA) -> 3x3 depthwise yunet_layer.py:30-36
+//   pool_fwd   max_pool2d(relu(bn(z)), 2)                        yunet_backbone.py:39-40
+//   upadd_fwd  relu(bn(a)) + nearest_up2(relu(bn(b)))            tfpn.py:39-40
+//
+// Train-mode BatchNorm is split across kernel boundaries: a producer writes its RAW conv
+// output z plus fp64 per-channel sum / sum-of-squares; every consumer applies
+// y = relu((z-mean)*scale+beta) while loading.  Each fused unit therefore reads its input
+// once and writes its output once (SURVEY.md 8d "unit-boundary traffic").
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- stem
+#define STEM_TW 32
+#define STEM_TH 8
+// one thread = one output pixel x 16 channels; the (2*TH+1)x(2*TW+1)x3 input patch is staged
+// in LDS from the NCHW image (coalesced along W).
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b,
+                                                       float* __restrict__ z,
+                                                       double* __restrict__ stats, int N, int H,
+                                                       int W) {
+    constexpr int PH = 2 * STEM_TH + 1, PW = 2 * STEM_TW + 1, PWS = PW + 1;
+    __shared__ float s_patch[3][PH][PWS];
+    __shared__ __attribute__((aligned(16))) float s_w[27][16];
+    __shared__ double s_red[4][32];
+    const int tid = threadIdx.x;
+    const int Ho = H / 2, Wo = W / 2;
+    for (int i = tid; i < 27 * 16; i += 256) {
+        const int co = i & 15, t = i >> 4;  // t = ci*9 + ky*3 + kx ; w is [16][3][3][3]
+        s_w[t][co] = w[co * 27 + t];
+    }
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = b[c];
+    double ssum[16], ssq[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ssum[c] = ssq[c] = 0.0;
+
+    const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, tiles_y = (Ho + STEM_TH - 1) / STEM_TH;
+    const int ntiles = N * tiles_x * tiles_y;
+    const int tx = tid % STEM_TW, ty = tid / STEM_TW;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y);
+        const int r = t - n * tiles_x * tiles_y;
+        const int y0 = (r / tiles_x) * STEM_TH, x0 = (r % tiles_x) * STEM_TW;
+        __syncthreads();
+        for (int i = tid; i < 3 * PH * PW; i += 256) {
+            const int ci = i / (PH * PW), q = i - ci * PH * PW;
+            const int py = q / PW, px = q - py * PW;
+            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+            float v = 0.0f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = img[(((size_t)n * 3 + ci) * H + iy) * W + ix];
+            s_patch[ci][py][px] = v;
+        }
+        __syncthreads();
+        const int oy = y0 + ty, ox = x0 + tx;
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = bias[c];
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = s_patch[ci][2 * ty + ky][2 * tx + kx];
+                    const float4* wr = reinterpret_cast<const float4*>(s_w[ci * 9 + ky * 3 + kx]);
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float4 ww = wr[c4];
+                        acc[c4 * 4 + 0] = fmaf(v, ww.x, acc[c4 * 4 + 0]);
+                        acc[c4 * 4 + 1] = fmaf(v, ww.y, acc[c4 * 4 + 1]);
+                        acc[c4 * 4 + 2] = fmaf(v, ww.z, acc[c4 * 4 + 2]);
+                        acc[c4 * 4 + 3] = fmaf(v, ww.w, acc[c4 * 4 + 3]);
+                    }
+                }
+        if (oy < Ho && ox < Wo) {
+            float4* dst = reinterpret_cast<float4*>(z + (((size_t)n * Ho + oy) * Wo + ox) * 16);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+                dst[c4] = make_float4(acc[c4 * 4], acc[c4 * 4 + 1], acc[c4 * 4 + 2], acc[c4 * 4 + 3]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                ssum[c] += (double)acc[c];
+                ssq[c] += (double)acc[c] * (double)acc[c];
+            }
+        }
+    }
+    // block reduction of the statistics: wave shuffles, then 4 waves through LDS
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double a = ssum[c], q = ssq[c];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            s_red[tid >> 6][c] = a;
+            s_red[tid >> 6][16 + c] = q;
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+        atomic_add_f64(&stats[tid], v);
+    }
+}
+
+// --------------------------------------------------------------------------- ConvDPUnit
+template <int CIN, int COUT, int TH, int TW>
+struct DpGeom {
+    static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_;
+    static constexpr int MT = (HP + 15) / 16, MP = MT * 16;
+    static constexpr int CM = CIN > COUT ? CIN : COUT;
+    static constexpr int LS = CM + 4;           // LDS row stride (floats), 16-byte aligned rows
+    static constexpr int C4I = CIN / 4, C4O = COUT / 4;
+    static constexpr int NT = COUT / 16, KS = CIN / 4;
+    static constexpr int PG = 256 / C4O;        // pixel groups in the depthwise phase
+    static constexpr int RG = PG / TW;          // row groups
+    static constexpr int RPT = TH / RG;         // output rows per thread
+    static constexpr size_t BUF_BYTES = (size_t)MP * LS * 4;
+    static constexpr size_t RED_BYTES = 256 * 8 * 8;
+    static constexpr size_t SMEM = (BUF_BYTES > RED_BYTES ? BUF_BYTES : RED_BYTES) + 3 * CIN * 4;
+    static_assert(PG % TW == 0 && TH % RG == 0, "tile / thread mapping");
+    static_assert(256 % C4I == 0, "load mapping");
+};
+
+template <int CIN, int COUT, int TH, int TW>
+__global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
+    using G = DpGeom<CIN, COUT, TH, TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* buf = reinterpret_cast<float*>(smem_raw);
+    constexpr size_t BUFB = G::BUF_BYTES > G::RED_BYTES ? G::BUF_BYTES : G::RED_BYTES;
+    float* s_coef = reinterpret_cast<float*>(smem_raw + BUFB);  // mean | scale | beta
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int H = d.H, W = d.W;
+    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
+
+    if (bn_in) {
+        for (int c = tid; c < CIN; c += 256) {
+            const BNCoef k = bn_coef(d.in_bn, CIN, c);
+            s_coef[c] = k.mean;
+            s_coef[CIN + c] = k.scale;
+            s_coef[2 * CIN + c] = k.beta;
+        }
+    }
+    // pointwise weights as MFMA B fragments, resident in registers for the whole kernel:
+    // B[k = ci][n = co] = w_pw[co][ci]
+    float Bf[G::KS][G::NT];
+    float bias_pw[G::NT];
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) {
+        bias_pw[nt] = d.b_pw[nt * 16 + l15];
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) Bf[s][nt] = d.w_pw[(nt * 16 + l15) * CIN + 4 * s + g];
+    }
+    // depthwise: this thread owns channels cq*4..cq*4+3
+    const int cq = tid % G::C4O, pg = tid / G::C4O;
+    const int dtx = pg % TW, r0 = (pg / TW) * G::RPT;
+    float4 w2[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        w2[t] = make_float4(d.w_dw[(cq * 4 + 0) * 9 + t], d.w_dw[(cq * 4 + 1) * 9 + t],
+                            d.w_dw[(cq * 4 + 2) * 9 + t], d.w_dw[(cq * 4 + 3) * 9 + t]);
+    const float4 b2 = *reinterpret_cast<const float4*>(d.b_dw + cq * 4);
+    double st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = 0.0;
+    __syncthreads();
+    const int lch4 = tid % G::C4I;  // input channel quad of this thread in the load phase
+    float4 cm = make_float4(0, 0, 0, 0), cs = cm, cb = cm;
+    if (bn_in) {
+        cm = *reinterpret_cast<const float4*>(s_coef + lch4 * 4);
+        cs = *reinterpret_cast<const float4*>(s_coef + CIN + lch4 * 4);
+        cb = *reinterpret_cast<const float4*>(s_coef + 2 * CIN + lch4 * 4);
+    }
+
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = d.N * tiles_x * tiles_y;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y);
+        const int rr = t - n * tiles_x * tiles_y;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const float* xin = d.x + (size_t)n * d.x_img_stride;
+        // ---- phase 1: haloed input tile -> LDS (input transform applied) ----------------------
+        for (int q = tid; q < G::HP * G::C4I; q += 256) {
+            const int hp = q / G::C4I;
+            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                v = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN + lch4 * 4);
+                if (bn_in) {
+                    v.x = bnrelu(v.x, cm.x, cs.x, cb.x);
+                    v.y = bnrelu(v.y, cm.y, cs.y, cb.y);
+                    v.z = bnrelu(v.z, cm.z, cs.z, cb.z);
+                    v.w = bnrelu(v.w, cm.w, cs.w, cb.w);
+                }
+            }
+            *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
+        }
+        if (G::MP > G::HP) {  // padding rows of the last M tile: keep them finite
+            for (int q = tid; q < (G::MP - G::HP) * G::C4I; q += 256) {
+                const int hp = G::HP + q / G::C4I;
+                *reinterpret_cast<float4*>(buf + hp * G::LS + (q % G::C4I) * 4) = make_float4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: pointwise 1x1 as [pixels x CIN] * [CIN x COUT] on the matrix cores,
+        //      result written back IN PLACE (a wave owns its 16-pixel M tiles) -------------------
+        for (int mt = wid; mt < G::MT; mt += 4) {
+            f32x4 acc[G::NT];
+#pragma unroll
+            for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* arow = buf + (mt * 16 + l15) * G::LS + g;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                const float a = arow[4 * s];
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a, Bf[s][nt], acc[nt]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hp = mt * 16 + 4 * g + r;
+                const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                // the depthwise conv zero-pads the POINTWISE OUTPUT: outside the image p = 0,
+                // not pw(0)+bias (SURVEY.md 7 "zero-halo trap")
+                const bool in = hp < G::HP && y >= 0 && y < H && x >= 0 && x < W;
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt)
+                    buf[hp * G::LS + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: depthwise 3x3 from LDS, bias, store raw z, BN statistics -----------------
+        {
+            float* zout = d.z + (size_t)n * d.z_img_stride;
+            const float* pbase = buf + dtx * G::LS + cq * 4;
+            float4 rowA[3], rowB[3], rowC[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                rowA[j] = *reinterpret_cast<const float4*>(pbase + ((r0 + 0) * G::HW_ + j) * G::LS);
+                rowB[j] = *reinterpret_cast<const float4*>(pbase + ((r0 + 1) * G::HW_ + j) * G::LS);
+            }
+#pragma unroll
+            for (int r = 0; r < G::RPT; ++r) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    rowC[j] = *reinterpret_cast<const float4*>(pbase + ((r0 + r + 2) * G::HW_ + j) * G::LS);
+                float4 o = b2;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    o.x = fmaf(rowA[j].x, w2[j].x, o.x); o.y = fmaf(rowA[j].y, w2[j].y, o.y);
+                    o.z = fmaf(rowA[j].z, w2[j].z, o.z); o.w = fmaf(rowA[j].w, w2[j].w, o.w);
+                    o.x = fmaf(rowB[j].x, w2[3 + j].x, o.x); o.y = fmaf(rowB[j].y, w2[3 + j].y, o.y);
+                    o.z = fmaf(rowB[j].z, w2[3 + j].z, o.z); o.w = fmaf(rowB[j].w, w2[3 + j].w, o.w);
+                    o.x = fmaf(rowC[j].x, w2[6 + j].x, o.x); o.y = fmaf(rowC[j].y, w2[6 + j].y, o.y);
+                    o.z = fmaf(rowC[j].z, w2[6 + j].z, o.z); o.w = fmaf(rowC[j].w, w2[6 + j].w, o.w);
+                }
+                const int y = y0 + r0 + r, x = x0 + dtx;
+                if (y < H && x < W) {
+                    *reinterpret_cast<float4*>(zout + ((size_t)y * W + x) * COUT + cq * 4) = o;
+                    st[0] += (double)o.x; st[1] += (double)o.y; st[2] += (double)o.z; st[3] += (double)o.w;
+                    st[4] += (double)o.x * o.x; st[5] += (double)o.y * o.y;
+                    st[6] += (double)o.z * o.z; st[7] += (double)o.w * o.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    rowA[j] = rowB[j];
+                    rowB[j] = rowC[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- BN statistics of this unit's output: block reduce in LDS, one fp64 atomic per channel
+    if (d.out_has_bn) {
+        double* red = reinterpret_cast<double*>(smem_raw);  // [256][8]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = st[i];
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, c = tid % COUT;  // 0: sum, 1: sumsq
+            const int q = c >> 2, k = (c & 3) + 4 * which;
+            double v = 0.0;
+            for (int p = 0; p < G::PG; ++p) v += red[(p * G::C4O + q) * 8 + k];
+            atomic_add_f64(const_cast<double*>(d.out_bn.stats) + which * COUT + c, v);
+        }
+    }
+}
+
+template <int CIN, int COUT, int TH, int TW>
+int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
+    using G = DpGeom<CIN, COUT, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+        attr_set = true;
+    }
+    const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
+    const int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW>), dim3(grid), dim3(256), G::SMEM, stream, *d);
+    return hip_status();
+}
+
+// ------------------------------------------------------------------- pool / upsample-add
+// one thread = one float4 of channels of one OUTPUT pixel
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ z, YunetBN bn,
+                                                       float* __restrict__ out, int N, int H, int W,
+                                                       int C) {
+    const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    // 256 % C4 == 0, so the channel quad of a thread is loop-invariant
+    const int c4 = threadIdx.x % C4;
+    BNCoef k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = bn_coef(bn, C, c4 * 4 + i);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        long long pix = e / C4;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
+        float4 m = make_float4(0, 0, 0, 0);  // relu output >= 0
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float4 v = *reinterpret_cast<const float4*>(
+                    z + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
+                m.x = fmaxf(m.x, bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta));
+                m.y = fmaxf(m.y, bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta));
+                m.z = fmaxf(m.z, bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta));
+                m.w = fmaxf(m.w, bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta));
+            }
+        *reinterpret_cast<float4*>(out + e * 4) = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void upadd_fwd_kernel(const float* __restrict__ za, YunetBN bna,
+                                                        const float* __restrict__ zb, YunetBN bnb,
+                                                        float* __restrict__ out, int N, int H, int W,
+                                                        int C) {
+    const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
+    const long long total = (long long)N * H * W * C4;
+    const int c4 = threadIdx.x % C4;
+    BNCoef ka[4], kb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ka[i] = bn_coef(bna, C, c4 * 4 + i);
+        kb[i] = bn_coef(bnb, C, c4 * 4 + i);
+    }
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        long long pix = e / C4;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int y = (int)(pix % H), n = (int)(pix / H);
+        const float4 a = *reinterpret_cast<const float4*>(za + e * 4);
+        const float4 b = *reinterpret_cast<const float4*>(
+            zb + (((size_t)n * Hb + y / 2) * Wb + x / 2) * C + c4 * 4);
+        float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = bnrelu(av[i], ka[i].mean, ka[i].scale, ka[i].beta) +
+                   bnrelu(bv[i], kb[i].mean, kb[i].scale, kb[i].beta);
+        *reinterpret_cast<float4*>(out + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// running_mean/var update of one BN layer (nn.BatchNorm2d momentum 0.1, unbiased var)
+__global__ void bn_running_kernel(const double* __restrict__ stats, float* __restrict__ rm,
+                                  float* __restrict__ rv, int C, int count, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double inv = 1.0 / (double)count;
+    const double mean = stats[c] * inv;
+    double var = stats[C + c] * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+    rm[c] = (1.0f - momentum) * rm[c] + momentum * (float)mean;
+    rv[c] = (1.0f - momentum) * rv[c] + momentum * (float)unb;
+}
+
+inline int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int yunet_stem_fwd(const float* img, const float* w, const float* b, float* z,
+                              double* stats, int N, int H, int W, int cmid, void* stream) {
+    if (cmid != 16 || (H & 1) || (W & 1)) return YUNET_EINVAL;
+    const int tiles = N * ((W / 2 + STEM_TW - 1) / STEM_TW) * ((H / 2 + STEM_TH - 1) / STEM_TH);
+    const int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, w, b, z,
+                       stats, N, H, W);
+    return hip_status();
+}
+
+extern "C" int yunet_dp_fwd(const YunetDP* d, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define DP_CASE(ci, co) \
+    if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
+    DP_CASE(16, 16)
+    DP_CASE(16, 32)
+    DP_CASE(16, 64)
+    DP_CASE(32, 32)
+    DP_CASE(32, 64)
+    DP_CASE(64, 64)
+    DP_CASE(64, 16)
+#undef DP_CASE
+    return YUNET_EINVAL;
+}
+
+extern "C" int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
+                              int C, void* stream) {
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z,
+                       *bn, out, N, H, W, C);
+    return hip_status();
+}
+
+extern "C" int yunet_upadd_fwd(const float* za, const YunetBN* bna, const float* zb,
+                               const YunetBN* bnb, float* out, int N, int H, int W, int C,
+                               void* stream) {
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, za,
+                       *bna, zb, *bnb, out, N, H, W, C);
+    return hip_status();
+}
+
+extern "C" int yunet_bn_update_running(const double* stats, float* running_mean,
+                                       float* running_var, int C, int count, float momentum,
+                                       void* stream) {
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       stats, running_mean, running_var, C, count, momentum);
+    return hip_status();
+}
+
+extern "C" int yunet_conv_blocks(void) { return CONV_BLOCKS; }
+extern "C" int yunet_abi_version(void) { return YUNET_ABI_VERSION; }

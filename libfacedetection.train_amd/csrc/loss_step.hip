@@ -1,0 +1,615 @@
+// loss_step.hip -- YuNet_Head loss step on gfx950: priors + decode + SimOTA assignment,
+// then the four losses with analytic gradients.  Compiled with -ffp-contract=off: the
+// reference evaluates mul and add as separate fp32 roundings (eager torch), and the
+// assignment is graded on integer outputs, so no FMA contraction is allowed here.
+//
+// Reference: mmdet/models/dense_heads/yunet_head.py:418-604,
+// mmdet/core/bbox/assigners/sim_ota_assigner.py:95-257,
+// mmdet/core/bbox/iou_calculators/iou2d_calculator.py:232-253,
+// mmdet/core/anchor/point_generator.py:80-175, mmdet/models/losses/*.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yunet_hip.h"
+
+#define ASSIGN_THREADS 1024
+#define ASSIGN_WAVES (ASSIGN_THREADS / 64)
+#define TOPK 10
+#define INF_COST 100000.0f
+
+namespace {
+
+struct Levels {
+    int n;
+    int h[YUNET_MAX_LEVELS], w[YUNET_MAX_LEVELS], s[YUNET_MAX_LEVELS], base[YUNET_MAX_LEVELS + 1];
+};
+
+__host__ Levels make_levels(const YunetLevels* lv) {
+    Levels L;
+    L.n = lv->num_levels;
+    int b = 0;
+    for (int i = 0; i < YUNET_MAX_LEVELS; ++i) {
+        L.h[i] = i < L.n ? lv->h[i] : 0;
+        L.w[i] = i < L.n ? lv->w[i] : 0;
+        L.s[i] = i < L.n ? lv->stride[i] : 1;
+        L.base[i] = b;
+        b += L.h[i] * L.w[i];
+    }
+    L.base[YUNET_MAX_LEVELS] = b;
+    return L;
+}
+
+// prior p -> (x*s, y*s, s): MlvlPointGenerator, offset 0, y-major, levels concatenated.
+__device__ __forceinline__ void prior_of(const Levels& L, int p, float& px, float& py, float& s) {
+    int w = L.w[0], st = L.s[0], base = 0;
+#pragma unroll
+    for (int i = 1; i < YUNET_MAX_LEVELS; ++i) {
+        const bool in = i < L.n && p >= L.base[i];
+        w = in ? L.w[i] : w;
+        st = in ? L.s[i] : st;
+        base = in ? L.base[i] : base;
+    }
+    const int q = p - base;
+    const int iy = q / w, ix = q - iy * w;
+    s = (float)st;
+    px = (float)ix * s;
+    py = (float)iy * s;
+}
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct GT {
+    float x1, y1, x2, y2;
+};
+
+// pairwise IoU exactly as bbox_overlaps (is_aligned=False, eps=1e-6)
+__device__ __forceinline__ float iou_of(float bx1, float by1, float bx2, float by2, const GT& g) {
+    float area1 = (bx2 - bx1) * (by2 - by1);
+    float area2 = (g.x2 - g.x1) * (g.y2 - g.y1);
+    float ltx = fmaxf(bx1, g.x1), lty = fmaxf(by1, g.y1);
+    float rbx = fminf(bx2, g.x2), rby = fminf(by2, g.y2);
+    float w = fmaxf(rbx - ltx, 0.0f), h = fmaxf(rby - lty, 0.0f);
+    float overlap = w * h;
+    float uni = (area1 + area2) - overlap;
+    uni = fmaxf(uni, 1e-6f);
+    return overlap / uni;
+}
+
+__device__ __forceinline__ bool in_gt_box(float cx, float cy, const GT& g) {
+    float l = cx - g.x1, t = cy - g.y1, r = g.x2 - cx, b = g.y2 - cy;
+    return fminf(fminf(l, t), fminf(r, b)) > 0.0f;
+}
+
+__device__ __forceinline__ bool in_gt_center(float cx, float cy, float s, float radius, const GT& g) {
+    float gcx = (g.x1 + g.x2) / 2.0f, gcy = (g.y1 + g.y2) / 2.0f;
+    float rs = radius * s;
+    float l = cx - (gcx - rs), t = cy - (gcy - rs);
+    float r = (gcx + rs) - cx, b = (gcy + rs) - cy;
+    return fminf(fminf(l, t), fminf(r, b)) > 0.0f;
+}
+
+// cost[v,g] = (cls_cost*1.0 + iou_cost*3.0) + (in_both ? 0 : 1e5)
+__device__ __forceinline__ float cost_of(float cls_cost, float iou, bool in_both) {
+    float iou_cost = -logf(iou + 1e-7f);
+    float c = cls_cost * 1.0f + iou_cost * 3.0f;
+    return c + (in_both ? 0.0f : INF_COST);
+}
+
+// order-preserving map float -> uint32 (handles the slightly negative costs of iou == 1)
+__device__ __forceinline__ uint32_t ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// scratch record of a valid prior (compacted, ascending prior index)
+struct __attribute__((aligned(16))) VRec {
+    float x1, y1, x2, y2;  // decoded box
+    float cls_cost, cx, cy, s;
+};
+
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
+    const float* __restrict__ flat, const float* __restrict__ gt_boxes,
+    const float* __restrict__ gt_kps, const int32_t* __restrict__ gt_labels,
+    const int32_t* __restrict__ gt_count, Levels L, int P, int Gmax, float radius,
+    int32_t* __restrict__ gt_inds, int32_t* __restrict__ labels, float* __restrict__ max_overlaps,
+    float* __restrict__ img_stats, VRec* __restrict__ scratch_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: gt[Gmax] | cnt[P] int | vidx[P] u16 | mg[P] u16 | misc
+    GT* s_gt = reinterpret_cast<GT*>(smem);
+    int* s_cnt = reinterpret_cast<int*>(s_gt + Gmax);
+    uint16_t* s_vidx = reinterpret_cast<uint16_t*>(s_cnt + P);
+    uint16_t* s_mg = s_vidx + ((P + 7) & ~7);
+    __shared__ int s_wave_off[ASSIGN_WAVES + 1];
+    __shared__ int s_V;
+    __shared__ float s_red[ASSIGN_WAVES][2];
+
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = min(gt_count[n], Gmax);
+    const float* fl = flat + (size_t)n * P * 16;
+    VRec* scratch = scratch_all + (size_t)n * P;
+
+    for (int g = tid; g < G; g += ASSIGN_THREADS) {
+        const float* b = gt_boxes + ((size_t)n * Gmax + g) * 4;
+        s_gt[g] = GT{b[0], b[1], b[2], b[3]};
+    }
+    if (tid == 0) s_V = 0;
+    __syncthreads();
+
+    // ---- phase A: decode, region tests, ordered compaction of the valid priors -------------
+    int vbase = 0;
+    for (int p0 = 0; p0 < P; p0 += ASSIGN_THREADS) {
+        const int p = p0 + tid;
+        bool valid = false;
+        VRec rec;
+        if (p < P) {
+            float px, py, s;
+            prior_of(L, p, px, py, s);
+            const float cx = px + s * 0.5f, cy = py + s * 0.5f;
+            for (int g = 0; g < G; ++g) {
+                const GT gt = s_gt[g];
+                if (in_gt_box(cx, cy, gt) || in_gt_center(cx, cy, s, radius, gt)) {
+                    valid = true;
+                    break;
+                }
+            }
+            gt_inds[(size_t)n * P + p] = 0;
+            max_overlaps[(size_t)n * P + p] = -INF_COST;
+            if (labels) labels[(size_t)n * P + p] = -1;
+            if (valid) {
+                const float4 a = *reinterpret_cast<const float4*>(fl + (size_t)p * 16);
+                const float2 b = *reinterpret_cast<const float2*>(fl + (size_t)p * 16 + 4);
+                // a = cls, dx, dy, dw ; b = dh, obj
+                const float bx = a.y * s + px, by = a.z * s + py;
+                const float bw = expf(a.w) * s, bh = expf(b.x) * s;
+                rec.x1 = bx - bw / 2.0f;
+                rec.y1 = by - bh / 2.0f;
+                rec.x2 = bx + bw / 2.0f;
+                rec.y2 = by + bh / 2.0f;
+                const float score = sigmoidf_ref(a.x) * sigmoidf_ref(b.y);
+                // F.binary_cross_entropy(sqrt(score), 1) = -max(log(sqrt(score)), -100)
+                rec.cls_cost = -fmaxf(logf(sqrtf(score)), -100.0f);
+                rec.cx = cx;
+                rec.cy = cy;
+                rec.s = s;
+            }
+        }
+        const unsigned long long bal = __ballot(valid);
+        const int wcnt = __popcll(bal);
+        if (lane == 0) s_wave_off[wid] = wcnt;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < ASSIGN_WAVES; ++w) {
+                int c = s_wave_off[w];
+                s_wave_off[w] = acc;
+                acc += c;
+            }
+            s_wave_off[ASSIGN_WAVES] = acc;
+        }
+        __syncthreads();
+        if (valid) {
+            const int v = vbase + s_wave_off[wid] + __popcll(bal & ((1ull << lane) - 1ull));
+            s_vidx[v] = (uint16_t)p;
+            s_cnt[v] = 0;
+            s_mg[v] = 0;
+            scratch[v] = rec;
+        }
+        vbase += s_wave_off[ASSIGN_WAVES];
+        __syncthreads();
+    }
+    const int V = vbase;
+    // scratch[] written by this block is read back by other waves of this block
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase B: one wave per GT: dynamic k from the top-10 IoUs, then the k cheapest -----
+    if (V > 0) {
+        for (int g = wid; g < G; g += ASSIGN_WAVES) {
+            const GT gt = s_gt[g];
+            float ti[TOPK];
+            float tc[TOPK];
+            int tv[TOPK];
+#pragma unroll
+            for (int i = 0; i < TOPK; ++i) {
+                ti[i] = -1.0f;
+                tc[i] = 3.0e38f;
+                tv[i] = 0x7fffffff;
+            }
+            for (int v = lane; v < V; v += 64) {
+                const VRec r = scratch[v];
+                float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
+                const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
+                float c = cost_of(r.cls_cost, iou, both);
+                int cv = v;
+                if (iou > ti[TOPK - 1]) {
+#pragma unroll
+                    for (int i = 0; i < TOPK; ++i) {
+                        const bool sw = iou > ti[i];
+                        const float t = ti[i];
+                        ti[i] = sw ? iou : t;
+                        iou = sw ? t : iou;
+                    }
+                }
+                if (c < tc[TOPK - 1]) {
+#pragma unroll
+                    for (int i = 0; i < TOPK; ++i) {
+                        const bool sw = c < tc[i];  // strict: equal costs keep ascending v
+                        const float t = tc[i];
+                        const int u = tv[i];
+                        tc[i] = sw ? c : t;
+                        tv[i] = sw ? cv : u;
+                        c = sw ? t : c;
+                        cv = sw ? u : cv;
+                    }
+                }
+            }
+            // merge: sum of the wave-wide top-10 IoUs in descending order
+            float sum = 0.0f;
+            const int K = V < TOPK ? V : TOPK;
+            for (int k = 0; k < K; ++k) {
+                const float m = wave_max_f(ti[0]);
+                const unsigned long long who = __ballot(ti[0] == m);
+                const int winner = __ffsll((long long)who) - 1;
+                if (lane == winner) {
+#pragma unroll
+                    for (int i = 0; i < TOPK - 1; ++i) ti[i] = ti[i + 1];
+                    ti[TOPK - 1] = -1.0f;
+                }
+                sum = sum + m;
+            }
+            int dk = (int)sum;  // .int(): truncation toward zero
+            dk = dk < 1 ? 1 : dk;
+            for (int k = 0; k < dk; ++k) {
+                const unsigned long long key = ((unsigned long long)ord(tc[0]) << 32) | (uint32_t)tv[0];
+                const unsigned long long kmin = wave_min_u64(key);
+                if (key == kmin && tv[0] != 0x7fffffff) {
+                    const int v = tv[0];
+                    atomicAdd(&s_cnt[v], 1);
+                    s_mg[v] = (uint16_t)g;
+#pragma unroll
+                    for (int i = 0; i < TOPK - 1; ++i) {
+                        tc[i] = tc[i + 1];
+                        tv[i] = tv[i + 1];
+                    }
+                    tc[TOPK - 1] = 3.0e38f;
+                    tv[TOPK - 1] = 0x7fffffff;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: conflicts -> argmin over ALL gts; outputs; per-image statistics ----------
+    float npos = 0.0f, wsum = 0.0f;
+    for (int v = tid; v < V; v += ASSIGN_THREADS) {
+        const int c = s_cnt[v];
+        if (c == 0) continue;
+        const VRec r = scratch[v];
+        int g = s_mg[v];
+        if (c > 1) {
+            float best = 3.0e38f;
+            for (int j = 0; j < G; ++j) {
+                const GT gt = s_gt[j];
+                const float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
+                const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
+                const float cj = cost_of(r.cls_cost, iou, both);
+                if (cj < best) {
+                    best = cj;
+                    g = j;
+                }
+            }
+        }
+        const float iou = iou_of(r.x1, r.y1, r.x2, r.y2, s_gt[g]);
+        const int p = s_vidx[v];
+        gt_inds[(size_t)n * P + p] = g + 1;
+        max_overlaps[(size_t)n * P + p] = iou;
+        if (labels) labels[(size_t)n * P + p] = gt_labels ? gt_labels[(size_t)n * Gmax + g] : 0;
+        const float* kp = gt_kps + ((size_t)n * Gmax + g) * 15;
+        // torch.mean over the 5 visibility flags
+        const float w = ((((kp[2] + kp[5]) + kp[8]) + kp[11]) + kp[14]) / 5.0f;
+        npos += 1.0f;
+        wsum += w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        npos += __shfl_xor(npos, o, 64);
+        wsum += __shfl_xor(wsum, o, 64);
+    }
+    if (lane == 0) {
+        s_red[wid][0] = npos;
+        s_red[wid][1] = wsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.0f, b = 0.0f;
+        for (int w = 0; w < ASSIGN_WAVES; ++w) {
+            a += s_red[w][0];
+            b += s_red[w][1];
+        }
+        img_stats[n * 2 + 0] = a;
+        img_stats[n * 2 + 1] = b;
+    }
+}
+
+__global__ void loss_norm_kernel(const float* __restrict__ img_stats, int N, float inv_world,
+                                 float* __restrict__ norm) {
+    __shared__ float s[2][256];
+    float a = 0.0f, b = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        a += img_stats[2 * i];
+        b += img_stats[2 * i + 1];
+    }
+    s[0][threadIdx.x] = a;
+    s[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + o];
+            s[1][threadIdx.x] += s[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        norm[0] = s[0][0] * inv_world;  // tensor.div_(world) before the all-reduce SUM
+        norm[1] = s[1][0];
+        norm[2] = s[0][0];              // rank-local positives (logging)
+    }
+}
+
+// ---- forward-mode dual numbers with 4 partials: the box loss is written once, in the
+// reference's evaluation order, and its gradient w.r.t. (dx,dy,dw,dh) falls out.
+struct D4 {
+    float v, d[4];
+};
+__device__ __forceinline__ D4 mk(float v) { return D4{v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) {
+    D4 r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) {
+    D4 r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
+    D4 r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+    D4 r; r.v = a.v / b.v;
+    const float inv = 1.0f / b.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return (a.v <= b.v) ? a : b; }
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return (a.v >= b.v) ? a : b; }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v > 0.0f ? a : mk(0.0f); }
+__device__ __forceinline__ D4 dscale(D4 a, float k) {
+    D4 r; r.v = a.v * k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * k;
+    return r;
+}
+__device__ __forceinline__ D4 dadd(D4 a, float k) { a.v = a.v + k; return a; }
+
+// eiou_loss, mmdet/models/losses/iou_loss.py:194-227
+__device__ D4 eiou(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float tx2f, float ty2f,
+                   float sp, float eps) {
+    const D4 tx1 = mk(tx1f), ty1 = mk(ty1f), tx2 = mk(tx2f), ty2 = mk(ty2f);
+    const D4 ex1 = dmin(px1, tx1), ey1 = dmin(py1, ty1);
+    const D4 ix1 = dmax(px1, tx1), iy1 = dmax(py1, ty1);
+    const D4 ix2 = dmin(px2, tx2), iy2 = dmin(py2, ty2);
+    const D4 xmin = dmin(ix1, ix2), ymin = dmin(iy1, iy2);
+    const D4 xmax = dmax(ix1, ix2), ymax = dmax(iy1, iy2);
+    const D4 inter = (((ix2 - ex1) * (iy2 - ey1) + (xmin - ex1) * (ymin - ey1)) -
+                      (ix1 - ex1) * (ymax - ey1)) - (xmax - ex1) * (iy1 - ey1);
+    const D4 uni = dadd(((px2 - px1) * (py2 - py1) + (tx2 - tx1) * (ty2 - ty1)) - inter, eps);
+    const D4 x = mk(1.0f) - inter / uni;
+    if (x.v < sp) return dscale(dscale(x * x, 0.5f), 1.0f / sp);   // 0.5*x^2/sp
+    return dadd(x, -0.5f * sp);
+}
+
+// diou_loss, mmdet/models/losses/iou_loss.py:137-172
+__device__ D4 diou(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float tx2f, float ty2f,
+                   float eps) {
+    const D4 tx1 = mk(tx1f), ty1 = mk(ty1f), tx2 = mk(tx2f), ty2 = mk(ty2f);
+    const D4 w = dclamp0(dmin(px2, tx2) - dmax(px1, tx1));
+    const D4 h = dclamp0(dmin(py2, ty2) - dmax(py1, ty1));
+    const D4 overlap = w * h;
+    const D4 ap = (px2 - px1) * (py2 - py1);
+    const D4 ag = (tx2 - tx1) * (ty2 - ty1);
+    const D4 uni = dadd((ap + ag) - overlap, eps);
+    const D4 ious = overlap / uni;
+    const D4 cw = dclamp0(dmax(px2, tx2) - dmin(px1, tx1));
+    const D4 ch = dclamp0(dmax(py2, ty2) - dmin(py1, ty1));
+    const D4 c2 = dadd(cw * cw + ch * ch, eps);
+    const D4 a = (tx1 + tx2) - (px1 + px2);
+    const D4 b = (ty1 + ty2) - (py1 + py2);
+    const D4 rho2 = dscale(a * a, 0.25f) + dscale(b * b, 0.25f);
+    return mk(1.0f) - (ious - rho2 / c2);
+}
+
+// log_sigmoid(x) = min(x,0) - log1p(exp(-|x|));  BCEWithLogits = (1-t)*x - log_sigmoid(x)
+__device__ __forceinline__ float bce_logits(float x, float t) {
+    const float ls = fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
+    return (1.0f - t) * x - ls;
+}
+
+#define LOSS_THREADS 256
+
+__global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
+    const float* __restrict__ flat, const int32_t* __restrict__ gt_inds,
+    const float* __restrict__ max_overlaps, const float* __restrict__ gt_boxes,
+    const float* __restrict__ gt_kps, Levels L, YunetLossCfg cfg, const float* __restrict__ norm,
+    int N, int P, int Gmax, float* __restrict__ dflat, float* __restrict__ partials) {
+    const float num_total = fmaxf(norm[0], 1.0f);
+    const float inv_total = 1.0f / num_total;
+    const float kps_den = norm[1] + 1.1920928955078125e-07f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long total = (long long)N * P;
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * LOSS_THREADS) {
+        const int n = (int)(e / P), p = (int)(e - (long long)n * P);
+        const float4* src = reinterpret_cast<const float4*>(flat + e * 16);
+        float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        float o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+        const int gi = gt_inds[e];
+        const float t_obj = gi > 0 ? 1.0f : 0.0f;
+        const float xo = q1.y;
+        acc[2] += bce_logits(xo, t_obj);
+        o[5] = cfg.w_obj * (sigmoidf_ref(xo) - t_obj) * inv_total;
+        if (gi > 0) {
+            const int g = gi - 1;
+            float px, py, s;
+            prior_of(L, p, px, py, s);
+            // cls: BCE with IoU soft target, positives only
+            const float t = max_overlaps[e];
+            acc[0] += bce_logits(q0.x, t);
+            o[0] = cfg.w_cls * (sigmoidf_ref(q0.x) - t) * inv_total;
+            // box: decode as duals w.r.t. (dx, dy, dw, dh)
+            D4 ddx = mk(q0.y), ddy = mk(q0.z), ddw = mk(q0.w), ddh = mk(q1.x);
+            ddx.d[0] = 1.f; ddy.d[1] = 1.f; ddw.d[2] = 1.f; ddh.d[3] = 1.f;
+            const D4 cx = dadd(dscale(ddx, s), px), cy = dadd(dscale(ddy, s), py);
+            D4 ew = mk(expf(ddw.v)), eh = mk(expf(ddh.v));
+            ew.d[2] = ew.v; eh.d[3] = eh.v;
+            const D4 bw = dscale(ew, s), bh = dscale(eh, s);
+            const D4 hx = dscale(bw, 0.5f), hy = dscale(bh, 0.5f);   // w/2 is exact
+            const D4 x1 = cx - hx, y1 = cy - hy, x2 = cx + hx, y2 = cy + hy;
+            const float* tb = gt_boxes + ((size_t)n * Gmax + g) * 4;
+            D4 lb = cfg.box_loss == YUNET_BOX_EIOU
+                        ? eiou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.smooth_point, cfg.box_eps)
+                        : diou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps);
+            acc[1] += lb.v;
+            const float kb = cfg.w_box * inv_total;
+            o[1] = lb.d[0] * kb; o[2] = lb.d[1] * kb; o[3] = lb.d[2] * kb; o[4] = lb.d[3] * kb;
+            // kps: smooth-L1 on (kps - prior_xy)/stride, weight = mean visibility
+            const float* kp = gt_kps + ((size_t)n * Gmax + g) * 15;
+            const float w = ((((kp[2] + kp[5]) + kp[8]) + kp[11]) + kp[14]) / 5.0f;
+            const float pr[10] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const float kk = cfg.w_kps / kps_den;
+            float lk = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float tgt = (kp[(j >> 1) * 3 + (j & 1)] - ((j & 1) ? py : px)) / s;
+                const float d = pr[j] - tgt;
+                const float ad = fabsf(d);
+                const bool quad = ad < cfg.kps_beta;
+                lk += (quad ? 0.5f * ad * ad / cfg.kps_beta : ad - 0.5f * cfg.kps_beta) * w;
+                const float gsl = quad ? d / cfg.kps_beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                o[6 + j] = gsl * w * kk;
+            }
+            acc[3] += lk;
+        }
+        float4* dst = reinterpret_cast<float4*>(dflat + e * 16);
+        dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+        dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+        dst[3] = make_float4(o[12], o[13], o[14], o[15]);
+    }
+    // deterministic block reduction -> one partial row per block
+    __shared__ float s_p[LOSS_THREADS / 64][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+        if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float v = 0.0f;
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) v += s_p[w][threadIdx.x];
+        // loss_i = weight * sum / normaliser
+        const float wgt = threadIdx.x == 0 ? cfg.w_cls : threadIdx.x == 1 ? cfg.w_box
+                          : threadIdx.x == 2 ? cfg.w_obj : cfg.w_kps;
+        const float den = threadIdx.x == 3 ? kps_den : num_total;
+        partials[blockIdx.x * 4 + threadIdx.x] = wgt * v / den;
+    }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partials, int blocks,
+                                     float* __restrict__ losses) {
+    // 4 waves, one per loss term; fp64 accumulation in a fixed order
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v = 0.0;
+    for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 4 + k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) losses[k] = (float)v;
+}
+
+}  // namespace
+
+extern "C" int yunet_loss_blocks(int N, int P) {
+    long long total = (long long)N * P;
+    long long b = (total + LOSS_THREADS - 1) / LOSS_THREADS;
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+extern "C" int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
+                            const int32_t* gt_labels, const int32_t* gt_count,
+                            const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
+                            int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                            float* img_stats, float* scratch, void* stream) {
+    if (!lv || lv->num_levels < 1 || lv->num_levels > YUNET_MAX_LEVELS || P > 65535 || N < 1 ||
+        Gmax < 1)
+        return YUNET_EINVAL;
+    Levels L = make_levels(lv);
+    if (L.base[YUNET_MAX_LEVELS] != P) return YUNET_EINVAL;
+    size_t lds = (size_t)Gmax * sizeof(GT) + (size_t)P * 4 + 2 * (size_t)((P + 7) & ~7) * 2;
+    lds = (lds + 15) & ~(size_t)15;
+    if (lds > 150 * 1024) return YUNET_EINVAL;
+    hipLaunchKernelGGL(assign_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, (hipStream_t)stream, flat,
+                       gt_boxes, gt_kps, gt_labels, gt_count, L, P, Gmax, center_radius, gt_inds,
+                       labels, max_overlaps, img_stats, reinterpret_cast<VRec*>(scratch));
+    return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_loss_norm(const float* img_stats, int N, float inv_world, float* norm,
+                               void* stream) {
+    hipLaunchKernelGGL(loss_norm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, img_stats, N,
+                       inv_world, norm);
+    return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_loss(const float* flat, const int32_t* gt_inds, const float* max_overlaps,
+                          const float* gt_boxes, const float* gt_kps, const YunetLevels* lv,
+                          const YunetLossCfg* cfg, const float* norm, int N, int P, int Gmax,
+                          float* dflat, float* partials, int blocks, void* stream) {
+    if (!lv || !cfg || blocks < 1) return YUNET_EINVAL;
+    Levels L = make_levels(lv);
+    if (L.base[YUNET_MAX_LEVELS] != P) return YUNET_EINVAL;
+    hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, flat,
+                       gt_inds, max_overlaps, gt_boxes, gt_kps, L, *cfg, norm, N, P, Gmax, dflat,
+                       partials);
+    return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_loss_finalize(const float* partials, int blocks, float* losses, void* stream) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials,
+                       blocks, losses);
+    return -(int)hipGetLastError();
+}
