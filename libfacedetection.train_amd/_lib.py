@@ -1,0 +1,121 @@
+"""ctypes binding of libyunet_hip.so (the C ABI declared in include/yunet_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing the product path
+raises.  Build it with `python __graft_entry__.py` or `make -C libfacedetection.train_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libyunet_hip.so')
+
+c_f32p = C.c_void_p
+MAX_LEVELS = 5
+
+T_IDENTITY, T_BNRELU = 0, 1
+BOX_EIOU, BOX_DIOU = 0, 1
+(OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
+ OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
+ OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET) = range(1, 18)
+
+
+class YunetBN(C.Structure):
+    _fields_ = [('stats', C.c_void_p), ('bstats', C.c_void_p), ('gamma', C.c_void_p),
+                ('beta', C.c_void_p), ('count', C.c_int32), ('eps', C.c_float)]
+
+
+class YunetDP(C.Structure):
+    _fields_ = [('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('cin', C.c_int32),
+                ('cout', C.c_int32), ('in_transform', C.c_int32), ('out_has_bn', C.c_int32),
+                ('accumulate_dx', C.c_int32), ('x_img_stride', C.c_int64),
+                ('z_img_stride', C.c_int64), ('x', C.c_void_p), ('in_bn', YunetBN),
+                ('w_pw', C.c_void_p), ('b_pw', C.c_void_p), ('w_dw', C.c_void_p),
+                ('b_dw', C.c_void_p), ('z', C.c_void_p), ('out_bn', YunetBN),
+                ('dy', C.c_void_p), ('dy_scale', C.c_void_p), ('dx', C.c_void_p),
+                ('wgrad_partials', C.c_void_p), ('wgrad_blocks', C.c_int32)]
+
+
+class YunetLevels(C.Structure):
+    _fields_ = [('num_levels', C.c_int32), ('h', C.c_int32 * MAX_LEVELS),
+                ('w', C.c_int32 * MAX_LEVELS), ('stride', C.c_int32 * MAX_LEVELS)]
+
+
+class YunetLossCfg(C.Structure):
+    _fields_ = [('box_loss', C.c_int32), ('w_cls', C.c_float), ('w_box', C.c_float),
+                ('w_obj', C.c_float), ('w_kps', C.c_float), ('box_eps', C.c_float),
+                ('smooth_point', C.c_float), ('kps_beta', C.c_float)]
+
+
+class YunetOp(C.Structure):
+    _fields_ = [('opcode', C.c_int32), ('i', C.c_int32 * 12), ('f', C.c_float * 8),
+                ('p', C.c_void_p * 12), ('bn', YunetBN * 2), ('dp', YunetDP),
+                ('lv', YunetLevels), ('loss', YunetLossCfg)]
+
+
+_SIGNATURES = {
+    'yunet_abi_version': (C.c_int, []),
+    'yunet_conv_blocks': (C.c_int, []),
+    'yunet_loss_blocks': (C.c_int, [C.c_int, C.c_int]),
+    'yunet_stem_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    'yunet_stem_bwd': (C.c_int, [C.c_void_p] * 3 + [C.POINTER(YunetBN), C.c_void_p] +
+                       [C.c_int] * 5 + [C.c_void_p]),
+    'yunet_dp_fwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
+    'yunet_dp_bwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
+    'yunet_pool_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 4 +
+                       [C.c_void_p]),
+    'yunet_pool_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p] +
+                       [C.c_int] * 5 + [C.c_void_p]),
+    'yunet_upadd_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.POINTER(YunetBN),
+                                  C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    'yunet_upadd_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.POINTER(YunetBN),
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] +
+                        [C.c_int] * 4 + [C.c_void_p]),
+    'yunet_bn_update_running': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float,
+                                                             C.c_void_p]),
+    'yunet_bn_param_grad': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
+    'yunet_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
+    'yunet_assign': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +
+                     [C.c_float] + [C.c_void_p] * 6),
+    'yunet_loss_norm': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    'yunet_loss': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels), C.POINTER(YunetLossCfg),
+                                                C.c_void_p] + [C.c_int] * 3 +
+                   [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
+                                                    C.c_float, C.c_int, C.c_void_p]),
+    'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
+}
+EXPORTED = sorted(_SIGNATURES)
+
+_lib = None
+
+
+class YunetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the kernel library (no GPU needed to load it); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YunetHipError(
+            f'{LIB_PATH} not found: the HIP extension is not built.  Run '
+            '`python __graft_entry__.py` (or `make -C libfacedetection.train_amd/csrc`). '
+            'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yunet_abi_version() != 1:
+        raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise YunetHipError(f'{what} failed with status {rc}')

@@ -1,0 +1,613 @@
+"""Fused YuNet training-step engine: the whole hot path as three replayable op lists.
+
+`forward_train` of the reference (mmdet/models/detectors/yunet.py:21-51) walks
+backbone -> TFPN -> head -> loss through ~76 eager conv/BN/ReLU ops and a Python loop
+over images; here the same step is a fixed sequence of HIP kernel launches, built once
+per input shape as an array of `YunetOp` and replayed by ONE C call per phase
+(`yunet_exec`):
+
+    fwd_a : stem, ConvDPUnits, pools, upsample-adds, fused heads, assign, loss_norm
+            [optional RCCL all-reduce of the scalar num_pos when world > 1]
+    fwd_b : loss (+ d loss / d preds), loss_finalize, BN running-stat updates
+    bwd   : head / ConvDPUnit / pool / upsample-add / stem backward, partial reductions,
+            BN parameter grads  -> one flat gradient buffer
+
+PyTorch supplies device memory, streams and torch.distributed only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ============================================================================ parameters
+class ParamLayout:
+    """Flat fp32 parameter buffer <-> reference state_dict names (OIHW shapes).
+
+    Every kernel unit owns a contiguous block  W_pw | b_pw | W_dw | b_dw [| gamma | beta]
+    (stem: W | b | gamma | beta) so a unit's weight-gradient partial row reduces straight
+    into the flat gradient buffer.  The four per-level head ConvDPUnits
+    (cls 1, bbox 4, obj 1, kps 10 channels; yunet_head.py:149-156) are stored as ONE fused
+    64->16 unit whose rows are the concatenation cls|bbox|obj|kps -- each reference
+    tensor is still a contiguous slice, so the state_dict contract is unchanged.
+    """
+
+    def __init__(self, arch):
+        self.arch = arch
+        self.entries = {}      # state_dict key -> (offset, shape)
+        self.units = {}        # unit name -> dict(off=..., cin, cout, bn=bool)
+        self.buffers = {}      # BN running buffers: key -> (index into bn list, kind)
+        self.bn_names = []     # BN prefixes in forward order
+        off = 0
+        st = arch['stage_channels']
+        cin0, cmid, _ = st[0]
+        assert cin0 == 3 and cmid == 16, 'stem kernel is specialised for 3->16'
+        # stem
+        self.units['stem'] = dict(off=off, cin=3, cout=cmid)
+        off = self._add('backbone.model0.conv1.weight', off, (cmid, 3, 3, 3))
+        off = self._add('backbone.model0.conv1.bias', off, (cmid,))
+        off = self._add('backbone.model0.bn1.weight', off, (cmid,))
+        off = self._add('backbone.model0.bn1.bias', off, (cmid,))
+        self.bn_names.append('backbone.model0.bn1')
+        for prefix, ci, co, with_bn in self.dp_units(arch, heads=False):
+            self.units[prefix] = dict(off=off, cin=ci, cout=co, bn=with_bn)
+            off = self._add(prefix + '.conv1.weight', off, (co, ci, 1, 1))
+            off = self._add(prefix + '.conv1.bias', off, (co,))
+            off = self._add(prefix + '.conv2.weight', off, (co, 1, 3, 3))
+            off = self._add(prefix + '.conv2.bias', off, (co,))
+            if with_bn:
+                off = self._add(prefix + '.bn.weight', off, (co,))
+                off = self._add(prefix + '.bn.bias', off, (co,))
+                self.bn_names.append(prefix + '.bn')
+        fc = arch['feat_channels']
+        kp = 2 * arch['kps_num']
+        self.head_rows = [('cls', 0, 1), ('bbox', 1, 4), ('obj', 5, 1), ('kps', 6, kp)]
+        self.head_cout = 6 + kp
+        assert self.head_cout == 16, 'fused head kernel is specialised for 16 outputs'
+        for l in range(len(arch['strides'])):
+            name = f'head.{l}'
+            self.units[name] = dict(off=off, cin=fc, cout=self.head_cout, bn=False)
+            base = off
+            for nm, r0, nr in self.head_rows:
+                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.weight'] = \
+                    (base + r0 * fc, (nr, fc, 1, 1))
+            base += self.head_cout * fc
+            for nm, r0, nr in self.head_rows:
+                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.bias'] = (base + r0, (nr,))
+            base += self.head_cout
+            for nm, r0, nr in self.head_rows:
+                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.weight'] = \
+                    (base + r0 * 9, (nr, 1, 3, 3))
+            base += self.head_cout * 9
+            for nm, r0, nr in self.head_rows:
+                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.bias'] = (base + r0, (nr,))
+            base += self.head_cout
+            off = base
+        self.numel = off
+
+    def _add(self, key, off, shape):
+        self.entries[key] = (off, tuple(shape))
+        return off + int(math.prod(shape))
+
+    @staticmethod
+    def dp_units(arch, heads=True):
+        out = []
+        st = arch['stage_channels']
+        out.append(('backbone.model0.conv2', st[0][1], st[0][2], True))
+        for i in range(1, len(st)):
+            ci, co = st[i]
+            out.append((f'backbone.model{i}.conv1', ci, ci, True))
+            out.append((f'backbone.model{i}.conv2', ci, co, True))
+        for i, c in enumerate(arch['neck_channels']):
+            out.append((f'neck.lateral_convs.{i}', c, c, True))
+        fc = arch['feat_channels']
+        for l in range(len(arch['strides'])):
+            for j in range(arch['shared_stacked_convs']):
+                out.append((f'bbox_head.multi_level_share_convs.{l}.{j}', fc, fc, True))
+        return out
+
+    def unit_ptrs(self, flat, name):
+        """device pointers (w_pw, b_pw, w_dw, b_dw, gamma, beta) of a ConvDPUnit block."""
+        u = self.units[name]
+        ci, co = u['cin'], u['cout']
+        base = flat.data_ptr() + 4 * u['off']
+        o = [0, co * ci, co * ci + co, co * ci + co + co * 9, co * ci + 2 * co + co * 9,
+             co * ci + 3 * co + co * 9]
+        return [base + 4 * x for x in o]
+
+    def unit_width(self, name):
+        u = self.units[name]
+        return K.dp_row_width(u['cin'], u['cout'])
+
+
+class FlatParams:
+    """Owns the flat parameter / gradient / momentum buffers and the BN running stats."""
+
+    def __init__(self, layout, device):
+        self.layout = layout
+        self.device = device
+        self.data = torch.zeros(layout.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(layout.numel, device=device, dtype=torch.float32)
+        nb = len(layout.bn_names)
+        self.bn_channels = []
+        for name in layout.bn_names:
+            self.bn_channels.append(layout.entries[name + '.weight'][1][0])
+        tot = sum(self.bn_channels)
+        self.running_mean = torch.zeros(tot, device=device, dtype=torch.float32)
+        self.running_var = torch.ones(tot, device=device, dtype=torch.float32)
+        self.num_batches_tracked = torch.zeros(nb, device=device, dtype=torch.int64)
+        self.bn_offset = {}
+        o = 0
+        for name, c in zip(layout.bn_names, self.bn_channels):
+            self.bn_offset[name] = o
+            o += c
+
+    def view(self, key, of=None):
+        off, shape = self.layout.entries[key]
+        buf = self.data if of is None else of
+        return buf[off:off + int(math.prod(shape))].view(shape)
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for key in self.layout.entries:
+                self.view(key).copy_(sd[key].to(self.device, torch.float32))
+            for i, name in enumerate(self.layout.bn_names):
+                o, c = self.bn_offset[name], self.bn_channels[i]
+                if name + '.running_mean' in sd:
+                    self.running_mean[o:o + c].copy_(sd[name + '.running_mean'])
+                    self.running_var[o:o + c].copy_(sd[name + '.running_var'])
+                if name + '.num_batches_tracked' in sd:
+                    self.num_batches_tracked[i] = int(sd[name + '.num_batches_tracked'])
+
+    def state_dict(self):
+        sd = {}
+        for key in self.layout.entries:
+            sd[key] = self.view(key).detach().clone()
+        for i, name in enumerate(self.layout.bn_names):
+            o, c = self.bn_offset[name], self.bn_channels[i]
+            sd[name + '.running_mean'] = self.running_mean[o:o + c].clone()
+            sd[name + '.running_var'] = self.running_var[o:o + c].clone()
+            sd[name + '.num_batches_tracked'] = self.num_batches_tracked[i].clone()
+        return sd
+
+
+# ================================================================================ engine
+class _T:
+    """An activation tensor of the plan: raw buffer (+ the BN its consumers must apply)."""
+
+    def __init__(self, buf, n, h, w, c, bn=None, img_stride=None):
+        self.buf, self.n, self.h, self.w, self.c, self.bn = buf, n, h, w, c, bn
+        self.img_stride = img_stride if img_stride is not None else h * w * c
+        self.grad = None
+        self.grad_written = False
+
+
+class _BNRef:
+    def __init__(self, name, c, count, stats, bstats, gamma_ptr, beta_ptr):
+        self.name, self.c, self.count = name, c, count
+        self.stats, self.bstats = stats, bstats      # (tensor views, fp64 [2c])
+        self.gamma_ptr, self.beta_ptr = gamma_ptr, beta_ptr
+
+    def c_struct(self):
+        return L.YunetBN(self.stats.data_ptr(), self.bstats.data_ptr(), self.gamma_ptr,
+                         self.beta_ptr, self.count, BN_EPS)
+
+
+_NULL_BN = L.YunetBN(None, None, None, None, 1, BN_EPS)
+
+
+class Plan:
+    """Buffers + op lists for one (N, H, W, Gmax) shape."""
+
+    def __init__(self, eng, n, h, w, gmax):
+        self.eng, self.n, self.h, self.w, self.gmax = eng, n, h, w, gmax
+        arch, lay, fp, dev = eng.arch, eng.layout, eng.params, eng.device
+        self.keep = []          # python objects that must outlive the op arrays
+        self.fwd_a, self.fwd_b, self.bwd = [], [], []
+        self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        # ---- BN statistic buffers: one fp64 block, zeroed by a single memset per step
+        tot_c = sum(fp.bn_channels)
+        self.stats = torch.zeros(4 * tot_c, device=dev, dtype=torch.float64)
+        self.bn = {}
+        o = 0
+        for name, c in zip(lay.bn_names, fp.bn_channels):
+            g_off = lay.entries[name + '.weight'][0]
+            b_off = lay.entries[name + '.bias'][0]
+            self.bn[name] = dict(c=c, stats=self.stats[o:o + 2 * c],
+                                 bstats=self.stats[2 * tot_c + o:2 * tot_c + o + 2 * c],
+                                 gamma=fp.data.data_ptr() + 4 * g_off,
+                                 beta=fp.data.data_ptr() + 4 * b_off,
+                                 dgamma=fp.grad.data_ptr() + 4 * g_off,
+                                 dbeta=fp.grad.data_ptr() + 4 * b_off)
+            o += 2 * c
+        self.ops_memset_stats = self._op(L.OP_MEMSET, p=[self.stats.data_ptr()],
+                                         i=self._split64(self.stats.numel() * 8))
+        self.fwd_a.append(self.ops_memset_stats)
+
+        # ---- loss-step geometry
+        strides = arch['strides']
+        self.sizes = [(h // s, w // s) for s in strides]
+        self.P = sum(a * b for a, b in self.sizes)
+        self.levels = K.make_levels(self.sizes, strides)
+        self.flat = torch.empty(n, self.P, 16, **f32)
+        self.dflat = torch.empty(n, self.P, 16, **f32)
+
+        # ---- conv stack
+        self.img_ptr_ops = []
+        st = arch['stage_channels']
+        cmid = st[0][1]
+        z0 = self._new_t(n, h // 2, w // 2, cmid, bn_name='backbone.model0.bn1')
+        self._stem(z0)
+        cur = self._dp(z0, 'backbone.model0.conv2')
+        taps = []
+        for i in range(len(st)):
+            if i > 0:
+                cur = self._dp(cur, f'backbone.model{i}.conv1')
+                cur = self._dp(cur, f'backbone.model{i}.conv2')
+            if i in arch['out_idx']:
+                taps.append(cur)
+            if i in arch['downsample_idx']:
+                cur = self._pool(cur)
+        feats = list(taps)
+        for i in range(len(feats) - 1, 0, -1):
+            feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
+            feats[i - 1] = self._upadd(feats[i - 1], feats[i])
+        feats[0] = self._dp(feats[0], 'neck.lateral_convs.0')
+        outs = [feats[i] for i in arch['neck_out_idx']]
+        assert [(t.h, t.w) for t in outs] == self.sizes, 'feature sizes vs strides'
+        base = 0
+        for l, f in enumerate(outs):
+            for j in range(arch['shared_stacked_convs']):
+                f = self._dp(f, f'bbox_head.multi_level_share_convs.{l}.{j}')
+            self._head(f, l, base)
+            base += f.h * f.w
+
+        # ---- loss step
+        self.gt_boxes = torch.zeros(n, gmax, 4, **f32)
+        self.gt_kps = torch.zeros(n, gmax, 5, 3, **f32)
+        self.gt_count = torch.zeros(n, device=dev, dtype=torch.int32)
+        self.gt_inds = torch.empty(n, self.P, device=dev, dtype=torch.int32)
+        self.max_overlaps = torch.empty(n, self.P, **f32)
+        self.img_stats = torch.empty(n, 2, **f32)
+        self.scratch = torch.empty(n, self.P, 8, **f32)
+        self.norm = torch.zeros(4, **f32)
+        self.losses = torch.zeros(4, **f32)
+        lib = L.load()
+        self.loss_blocks = lib.yunet_loss_blocks(n, self.P)
+        self.loss_partials = torch.empty(self.loss_blocks, 4, **f32)
+        self.dy_scale = torch.ones(16, **f32)
+        op = self._op(L.OP_ASSIGN,
+                      p=[self.flat.data_ptr(), self.gt_boxes.data_ptr(), self.gt_kps.data_ptr(),
+                         None, self.gt_count.data_ptr(), self.gt_inds.data_ptr(), None,
+                         self.max_overlaps.data_ptr(), self.img_stats.data_ptr(),
+                         self.scratch.data_ptr()],
+                      i=[n, self.P, gmax], f=[arch['center_radius']])
+        op.lv = self.levels
+        self.fwd_a.append(op)
+        self.fwd_a.append(self._op(L.OP_LOSS_NORM, p=[self.img_stats.data_ptr(),
+                                                     self.norm.data_ptr()],
+                                   i=[n], f=[1.0 / eng.world_size]))
+        op = self._op(L.OP_LOSS,
+                      p=[self.flat.data_ptr(), self.gt_inds.data_ptr(),
+                         self.max_overlaps.data_ptr(), self.gt_boxes.data_ptr(),
+                         self.gt_kps.data_ptr(), self.norm.data_ptr(), self.dflat.data_ptr(),
+                         self.loss_partials.data_ptr()],
+                      i=[n, self.P, gmax, self.loss_blocks])
+        op.lv = self.levels
+        op.loss = K.make_loss_cfg(arch['loss_bbox'], arch['loss_cls_weight'],
+                                  arch['loss_bbox_weight'], arch['loss_obj_weight'],
+                                  arch['loss_kps_weight'], 1e-6, 0.1, arch['kps_beta'])
+        self.fwd_b.append(op)
+        self.fwd_b.append(self._op(L.OP_LOSS_FINALIZE, p=[self.loss_partials.data_ptr(),
+                                                         self.losses.data_ptr()],
+                                   i=[self.loss_blocks]))
+        # BN running statistics (nn.BatchNorm2d momentum 0.1)
+        for name in lay.bn_names:
+            b = self.bn[name]
+            o2 = fp.bn_offset[name]
+            cnt = self.bn_count[name]
+            self.fwd_b.append(self._op(
+                L.OP_BN_RUNNING,
+                p=[b['stats'].data_ptr(), fp.running_mean.data_ptr() + 4 * o2,
+                   fp.running_var.data_ptr() + 4 * o2], i=[b['c'], cnt], f=[BN_MOMENTUM]))
+
+        # ---- backward: reverse of the forward nodes
+        for node in reversed(self.bwd_nodes):
+            node()
+        for name in lay.bn_names:
+            b = self.bn[name]
+            self.bwd.append(self._op(L.OP_BN_PARAM_GRAD,
+                                     p=[b['bstats'].data_ptr(), b['dgamma'], b['dbeta']],
+                                     i=[b['c'], 0]))
+        self.c_fwd_a = self._carray(self.fwd_a)
+        self.c_fwd_b = self._carray(self.fwd_b)
+        self.c_bwd = self._carray(self.bwd)
+
+    # ------------------------------------------------------------------ helpers
+    bn_count = None
+
+    @staticmethod
+    def _split64(v):
+        return [v & 0xffffffff if (v & 0xffffffff) < 2 ** 31 else (v & 0xffffffff) - 2 ** 32,
+                (v >> 32) & 0x7fffffff]
+
+    def _op(self, opcode, p=(), i=(), f=()):
+        op = L.YunetOp()
+        op.opcode = opcode
+        for k, v in enumerate(p):
+            op.p[k] = v
+        for k, v in enumerate(i):
+            op.i[k] = int(v)
+        for k, v in enumerate(f):
+            op.f[k] = float(v)
+        return op
+
+    def _carray(self, ops):
+        arr = (L.YunetOp * len(ops))()
+        for k, op in enumerate(ops):
+            C.memmove(C.byref(arr, k * C.sizeof(L.YunetOp)), C.byref(op), C.sizeof(L.YunetOp))
+        return arr
+
+    def _bn_struct(self, name, count):
+        if self.bn_count is None:
+            self.bn_count = {}
+        self.bn_count[name] = count
+        b = self.bn[name]
+        return L.YunetBN(b['stats'].data_ptr(), b['bstats'].data_ptr(), b['gamma'], b['beta'],
+                         count, BN_EPS)
+
+    def _new_t(self, n, h, w, c, bn_name=None):
+        buf = torch.empty(n, h, w, c, device=self.eng.device, dtype=torch.float32)
+        t = _T(buf, n, h, w, c, bn=bn_name)
+        return t
+
+    def _grad_of(self, t):
+        """(grad buffer, accumulate flag) for a consumer's backward; first writer overwrites."""
+        if t.grad is None:
+            t.grad = torch.empty_like(t.buf)
+        acc = t.grad_written
+        t.grad_written = True
+        return t.grad, int(acc)
+
+    # ------------------------------------------------------------------ nodes
+    def _stem(self, z0):
+        lay, fp = self.eng.layout, self.eng.params
+        u = lay.units['stem']
+        wp = fp.data.data_ptr() + 4 * u['off']
+        bp = wp + 4 * 16 * 27
+        bn = self.bn['backbone.model0.bn1']
+        cnt = z0.n * z0.h * z0.w
+        self._bn_struct('backbone.model0.bn1', cnt)
+        op = self._op(L.OP_STEM_FWD, p=[None, wp, bp, z0.buf.data_ptr(), bn['stats'].data_ptr()],
+                      i=[self.n, self.h, self.w, 16])
+        self.fwd_a.append(op)
+        self.img_ptr_ops.append(('fwd_a', len(self.fwd_a) - 1))
+        blocks = K.stem_grid(self.n, self.h, self.w)
+        width = 16 * 27 + 16
+        part = torch.empty(blocks, width, device=self.eng.device, dtype=torch.float32)
+        self.keep.append(part)
+        gptr = fp.grad.data_ptr() + 4 * u['off']
+
+        def bwd():
+            assert z0.grad is not None
+            op = self._op(L.OP_STEM_BWD, p=[None, z0.buf.data_ptr(), z0.grad.data_ptr(),
+                                            part.data_ptr()],
+                          i=[self.n, self.h, self.w, 16, blocks])
+            op.bn[0] = self._bn_struct('backbone.model0.bn1', cnt)
+            self.bwd.append(op)
+            self.img_ptr_ops.append(('bwd', len(self.bwd) - 1))
+            self.bwd.append(self._op(L.OP_REDUCE_PARTIALS, p=[part.data_ptr(), gptr],
+                                     i=[blocks, width, 0]))
+        self.bwd_nodes.append(bwd)
+
+    def _dp_desc(self, x, name, z, z_img_stride=None):
+        lay, fp = self.eng.layout, self.eng.params
+        u = lay.units[name]
+        d = L.YunetDP()
+        d.N, d.H, d.W, d.cin, d.cout = x.n, x.h, x.w, u['cin'], u['cout']
+        assert x.c == u['cin']
+        d.in_transform = L.T_BNRELU if x.bn is not None else L.T_IDENTITY
+        d.out_has_bn = 1 if u['bn'] else 0
+        d.x_img_stride = x.img_stride
+        d.z_img_stride = z_img_stride if z_img_stride is not None else x.h * x.w * u['cout']
+        d.x = x.buf.data_ptr()
+        d.in_bn = self._bn_struct(x.bn, x.n * x.h * x.w) if x.bn is not None else _NULL_BN
+        ptrs = lay.unit_ptrs(fp.data, name)
+        d.w_pw, d.b_pw, d.w_dw, d.b_dw = ptrs[0], ptrs[1], ptrs[2], ptrs[3]
+        d.z = z
+        bn_name = name + '.bn' if u['bn'] else None
+        d.out_bn = self._bn_struct(bn_name, x.n * x.h * x.w) if bn_name else _NULL_BN
+        return d, u, bn_name
+
+    def _dp(self, x, name):
+        u = self.eng.layout.units[name]
+        z = self._new_t(x.n, x.h, x.w, u['cout'], bn_name=name + '.bn')
+        self._dp_node(x, name, z.buf.data_ptr(), None, z)
+        return z
+
+    def _head(self, x, level, base):
+        name = f'head.{level}'
+        zptr = self.flat.data_ptr() + 4 * base * 16
+        self._dp_node(x, name, zptr, self.P * 16, None, dy_ptr=self.dflat.data_ptr() + 4 * base * 16)
+
+    def _dp_node(self, x, name, zptr, z_img_stride, zt, dy_ptr=None):
+        d, u, bn_name = self._dp_desc(x, name, zptr, z_img_stride)
+        op = self._op(L.OP_DP_FWD)
+        op.dp = d
+        self.fwd_a.append(op)
+        blocks = K.dp_grid(x.n, x.h, x.w)
+        width = K.dp_row_width(u['cin'], u['cout'])
+        part = torch.empty(blocks, width, device=self.eng.device, dtype=torch.float32)
+        self.keep.append(part)
+        gptr = self.eng.params.grad.data_ptr() + 4 * u['off']
+
+        def bwd():
+            d2, _, _ = self._dp_desc(x, name, zptr, z_img_stride)
+            if zt is not None:
+                assert zt.grad is not None, f'{name}: output has no gradient'
+                d2.dy = zt.grad.data_ptr()
+                d2.dy_scale = None
+            else:
+                d2.dy = dy_ptr
+                d2.dy_scale = self.dy_scale.data_ptr()
+            gx, acc = self._grad_of(x)
+            d2.dx = gx.data_ptr()
+            d2.accumulate_dx = acc
+            d2.wgrad_partials, d2.wgrad_blocks = part.data_ptr(), blocks
+            op = self._op(L.OP_DP_BWD)
+            op.dp = d2
+            self.bwd.append(op)
+            self.bwd.append(self._op(L.OP_REDUCE_PARTIALS, p=[part.data_ptr(), gptr],
+                                     i=[blocks, width, 0]))
+        self.bwd_nodes.append(bwd)
+
+    def _pool(self, x):
+        out = self._new_t(x.n, x.h // 2, x.w // 2, x.c, bn_name=None)
+        cnt = x.n * x.h * x.w
+        op = self._op(L.OP_POOL_FWD, p=[x.buf.data_ptr(), out.buf.data_ptr()],
+                      i=[x.n, x.h, x.w, x.c])
+        op.bn[0] = self._bn_struct(x.bn, cnt)
+        self.fwd_a.append(op)
+
+        def bwd():
+            gx, acc = self._grad_of(x)
+            op = self._op(L.OP_POOL_BWD, p=[x.buf.data_ptr(), out.grad.data_ptr(), gx.data_ptr()],
+                          i=[x.n, x.h, x.w, x.c, acc])
+            op.bn[0] = self._bn_struct(x.bn, cnt)
+            self.bwd.append(op)
+        self.bwd_nodes.append(bwd)
+        return out
+
+    def _upadd(self, a, b):
+        assert a.bn is not None and b.bn is not None and a.h == 2 * b.h and a.w == 2 * b.w
+        out = self._new_t(a.n, a.h, a.w, a.c, bn_name=None)
+        op = self._op(L.OP_UPADD_FWD, p=[a.buf.data_ptr(), b.buf.data_ptr(), out.buf.data_ptr()],
+                      i=[a.n, a.h, a.w, a.c])
+        op.bn[0] = self._bn_struct(a.bn, a.n * a.h * a.w)
+        op.bn[1] = self._bn_struct(b.bn, b.n * b.h * b.w)
+        self.fwd_a.append(op)
+
+        def bwd():
+            ga, acc_a = self._grad_of(a)
+            gb, acc_b = self._grad_of(b)
+            op = self._op(L.OP_UPADD_BWD,
+                          p=[a.buf.data_ptr(), b.buf.data_ptr(), out.grad.data_ptr(),
+                             ga.data_ptr(), gb.data_ptr()],
+                          i=[a.n, a.h, a.w, a.c, acc_a, acc_b])
+            op.bn[0] = self._bn_struct(a.bn, a.n * a.h * a.w)
+            op.bn[1] = self._bn_struct(b.bn, b.n * b.h * b.w)
+            self.bwd.append(op)
+        self.bwd_nodes.append(bwd)
+        return out
+
+    def set_img(self, img):
+        ptr = img.data_ptr()
+        for which, idx in self.img_ptr_ops:
+            arr = {'fwd_a': self.c_fwd_a, 'bwd': self.c_bwd}[which]
+            arr[idx].p[0] = ptr
+
+
+class YuNetEngine:
+    """Runs the YuNet training step of one rank; see module docstring."""
+
+    def __init__(self, arch, device, world_size=1, process_group=None):
+        self.arch = dict(arch)
+        self.device = torch.device(device)
+        self.layout = ParamLayout(arch)
+        self.params = FlatParams(self.layout, self.device)
+        self.world_size = world_size
+        self.process_group = process_group
+        self.plans = {}
+        self.plan = None
+        self.lib = L.load()
+        self._host_idx = {}
+
+    # ------------------------------------------------------------------ GT staging
+    def stage_gt(self, plan, gt_bboxes, gt_keypointss):
+        """Ragged per-image lists -> padded device buffers with O(1) kernel launches."""
+        n = plan.n
+        counts = [int(b.shape[0]) for b in gt_bboxes]
+        tot = sum(counts)
+        plan.gt_count.copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=True)
+        if tot == 0:
+            return
+        img_idx = torch.repeat_interleave(torch.arange(n), torch.tensor(counts))
+        slot = torch.cat([torch.arange(c) for c in counts]) if tot else torch.zeros(0, dtype=torch.int64)
+        lin = (img_idx * plan.gmax + slot).to(self.device, non_blocking=True)
+        boxes = torch.cat([b.reshape(-1, 4) for b in gt_bboxes]).to(self.device, torch.float32)
+        kps = torch.cat([k.reshape(-1, 15) for k in gt_keypointss]).to(self.device, torch.float32)
+        plan.gt_boxes.view(-1, 4).index_copy_(0, lin, boxes)
+        plan.gt_kps.view(-1, 15).index_copy_(0, lin, kps)
+
+    def get_plan(self, n, h, w, max_gt):
+        gmax = 64
+        while gmax < max_gt:
+            gmax *= 2
+        key = (n, h, w, gmax)
+        if key not in self.plans:
+            if h % 32 or w % 32:
+                raise ValueError('input height/width must be multiples of 32 (reference: '
+                                 'max_pool2d(2) x4 + nearest x2 upsampling must line up)')
+            self.plans[key] = Plan(self, n, h, w, gmax)
+        return self.plans[key]
+
+    def _exec(self, arr, what):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.yunet_exec(arr, len(arr), stream), what)
+
+    # ------------------------------------------------------------------ step phases
+    def forward(self, img, gt_bboxes, gt_keypointss):
+        """img [N,3,H,W] fp32 CUDA; GT ragged lists.  Returns the device tensor
+        losses[4] = (loss_cls, loss_bbox, loss_obj, loss_kps)."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        n, _, h, w = img.shape
+        max_gt = max([int(b.shape[0]) for b in gt_bboxes] + [1])
+        plan = self.get_plan(n, h, w, max_gt)
+        self.plan = plan
+        self._img = img
+        self.stage_gt(plan, gt_bboxes, gt_keypointss)
+        plan.set_img(img)
+        self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')
+        if self.world_size > 1:
+            # reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74): each rank holds
+            # num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound.
+            torch.distributed.all_reduce(plan.norm[0:1], group=self.process_group)
+        self._exec(plan.c_fwd_b, 'yunet_exec(fwd_b)')
+        self.params.num_batches_tracked += 1
+        return plan.losses
+
+    def backward(self, grad_scales=None):
+        """d(sum_i s_i * loss_i)/d(params) -> params.grad (overwritten)."""
+        plan = self.plan
+        if grad_scales is not None:
+            s = [float(v) for v in grad_scales]
+            vec = [s[0]] + [s[1]] * 4 + [s[2]] + [s[3]] * 10
+            plan.dy_scale.copy_(torch.tensor(vec, dtype=torch.float32), non_blocking=True)
+        self._exec(plan.c_bwd, 'yunet_exec(bwd)')
+
+    def allreduce_grads(self, async_op=False):
+        """DDP gradient mean: ONE collective over the flat 303 KB (n) / 218 KB (s) buffer."""
+        if self.world_size <= 1:
+            return None
+        return torch.distributed.all_reduce(self.params.grad, group=self.process_group,
+                                            async_op=async_op)
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def forward_features(self, img):
+        """Train-mode conv stack only -> flat [N,P,16] (used by tests)."""
+        n, _, h, w = img.shape
+        plan = self.get_plan(n, h, w, 1)
+        self.plan = plan
+        plan.set_img(img)
+        plan.gt_count.zero_()
+        self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')
+        return plan.flat

@@ -1,0 +1,264 @@
+"""Tensor-level wrappers of the C ABI (one call = one kernel launch on torch's current stream).
+
+PyTorch is only the container here: tensors are allocated with torch, their `data_ptr()`s
+are handed to libyunet_hip.so.  Layout conventions: activations NHWC fp32 contiguous,
+parameters in the reference's OIHW shapes (made contiguous 2-D views on the fly).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+                'expected a contiguous fp32 CUDA tensor'
+
+
+class BN:
+    """Python-side YunetBN: keeps the tensors alive while the descriptor is in use."""
+
+    def __init__(self, stats, gamma, beta, count, eps=1e-5, bstats=None):
+        assert stats.dtype == torch.float64 and stats.numel() == 2 * gamma.numel()
+        self.stats, self.gamma, self.beta, self.bstats = stats, gamma, beta, bstats
+        self.count, self.eps = int(count), float(eps)
+
+    def c(self):
+        return L.YunetBN(self.stats.data_ptr(), self.bstats.data_ptr() if self.bstats is not None
+                         else None, self.gamma.data_ptr(), self.beta.data_ptr(), self.count,
+                         self.eps)
+
+
+_NULL_BN = L.YunetBN(None, None, None, None, 1, 1e-5)
+
+
+def conv_blocks():
+    return L.load().yunet_conv_blocks()
+
+
+def dp_grid(n, h, w):
+    tiles = n * ((w + 15) // 16) * ((h + 7) // 8)
+    return min(tiles, conv_blocks())
+
+
+def stem_grid(n, h, w):
+    tiles = n * ((w // 2 + 31) // 32) * ((h // 2 + 7) // 8)
+    return min(tiles, conv_blocks())
+
+
+def dp_row_width(cin, cout):
+    return cout * cin + cout + cout * 9 + cout
+
+
+def stem_fwd(img, w, b, stats):
+    """img [N,3,H,W] NCHW -> raw z [N,H/2,W/2,16] NHWC; accumulates stats (fp64 [32])."""
+    _chk_f32(img, w, b)
+    n, _, h, ww = img.shape
+    z = torch.empty(n, h // 2, ww // 2, 16, device=img.device, dtype=torch.float32)
+    L.check(L.load().yunet_stem_fwd(_p(img), _p(w), _p(b), _p(z), _p(stats), n, h, ww, 16,
+                                    _stream()), 'yunet_stem_fwd')
+    return z
+
+
+def stem_bwd(img, z, dy, bn):
+    """-> (dw [16,3,3,3], db [16]) given dy = grad wrt bn1 output (ReLU-masked)."""
+    n, _, h, w = img.shape
+    blocks = stem_grid(n, h, w)
+    width = 16 * 27 + 16
+    part = torch.empty(blocks, width, device=img.device, dtype=torch.float32)
+    bnc = bn.c()
+    L.check(L.load().yunet_stem_bwd(_p(img), _p(z), _p(dy), C.byref(bnc), _p(part), blocks, n, h,
+                                    w, 16, _stream()), 'yunet_stem_bwd')
+    out = torch.empty(width, device=img.device, dtype=torch.float32)
+    reduce_partials(part, out)
+    return out[:432].view(16, 3, 3, 3), out[432:]
+
+
+def reduce_partials(part, out, accumulate=False):
+    L.check(L.load().yunet_reduce_partials(_p(part), part.shape[0], part.shape[1], _p(out),
+                                           int(accumulate), _stream()), 'yunet_reduce_partials')
+
+
+def _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, x_img_stride=None,
+             z_img_stride=None):
+    n, h, w, cin = x.shape
+    cout = w_pw.shape[0]
+    d = L.YunetDP()
+    d.N, d.H, d.W, d.cin, d.cout = n, h, w, cin, cout
+    d.in_transform = L.T_BNRELU if in_bn is not None else L.T_IDENTITY
+    d.out_has_bn = 1 if out_bn is not None else 0
+    d.x_img_stride = x_img_stride if x_img_stride is not None else h * w * cin
+    d.z_img_stride = z_img_stride if z_img_stride is not None else h * w * cout
+    d.x = x.data_ptr()
+    d.in_bn = in_bn.c() if in_bn is not None else _NULL_BN
+    d.out_bn = out_bn.c() if out_bn is not None else _NULL_BN
+    d.w_pw, d.b_pw, d.w_dw, d.b_dw = (w_pw.data_ptr(), b_pw.data_ptr(), w_dw.data_ptr(),
+                                     b_dw.data_ptr())
+    d.z = z.data_ptr()
+    return d
+
+
+def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_stride=None):
+    """ConvDPUnit forward.  x [N,H,W,Cin] raw producer output (in_bn given) or activations.
+    Returns raw z [N,H,W,Cout]; accumulates out_bn.stats when out_bn is given."""
+    _chk_f32(x, w_pw, b_pw, w_dw, b_dw)
+    n, h, w, _ = x.shape
+    cout = w_pw.shape[0]
+    if z is None:
+        z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    d = _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, z_img_stride=z_img_stride)
+    L.check(L.load().yunet_dp_fwd(C.byref(d), _stream()), 'yunet_dp_fwd')
+    return z
+
+
+def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=None,
+           dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True):
+    """ConvDPUnit backward.  Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw)."""
+    _chk_f32(x, w_pw, b_pw, w_dw, b_dw, dy)
+    n, h, w, cin = x.shape
+    cout = w_pw.shape[0]
+    if dx is None and need_dx:
+        dx = torch.empty_like(x)
+    d = _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, z_img_stride=z_img_stride)
+    d.dy = dy.data_ptr()
+    d.dy_scale = dy_scale.data_ptr() if dy_scale is not None else None
+    d.dx = dx.data_ptr() if dx is not None else None
+    d.accumulate_dx = int(accumulate_dx)
+    blocks = dp_grid(n, h, w)
+    width = dp_row_width(cin, cout)
+    part = torch.empty(blocks, width, device=x.device, dtype=torch.float32)
+    d.wgrad_partials, d.wgrad_blocks = part.data_ptr(), blocks
+    L.check(L.load().yunet_dp_bwd(C.byref(d), _stream()), 'yunet_dp_bwd')
+    out = torch.empty(width, device=x.device, dtype=torch.float32)
+    reduce_partials(part, out)
+    o1, o2, o3 = cout * cin, cout * cin + cout, cout * cin + cout + cout * 9
+    return (dx, out[:o1].view(cout, cin, 1, 1), out[o1:o2], out[o2:o3].view(cout, 1, 3, 3),
+            out[o3:])
+
+
+def pool_fwd(z, bn):
+    n, h, w, c = z.shape
+    out = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)
+    bnc = bn.c()
+    L.check(L.load().yunet_pool_fwd(_p(z), C.byref(bnc), _p(out), n, h, w, c, _stream()),
+            'yunet_pool_fwd')
+    return out
+
+
+def pool_bwd(z, bn, dy_out, dx=None, accumulate=False):
+    n, h, w, c = z.shape
+    if dx is None:
+        dx = torch.empty_like(z)
+    bnc = bn.c()
+    L.check(L.load().yunet_pool_bwd(_p(z), C.byref(bnc), _p(dy_out), _p(dx), int(accumulate), n, h,
+                                    w, c, _stream()), 'yunet_pool_bwd')
+    return dx
+
+
+def upadd_fwd(za, bna, zb, bnb):
+    n, h, w, c = za.shape
+    out = torch.empty_like(za)
+    a, b = bna.c(), bnb.c()
+    L.check(L.load().yunet_upadd_fwd(_p(za), C.byref(a), _p(zb), C.byref(b), _p(out), n, h, w, c,
+                                     _stream()), 'yunet_upadd_fwd')
+    return out
+
+
+def upadd_bwd(za, bna, zb, bnb, dout, dxa=None, acc_a=False, dxb=None, acc_b=False):
+    n, h, w, c = za.shape
+    dxa = torch.empty_like(za) if dxa is None else dxa
+    dxb = torch.empty_like(zb) if dxb is None else dxb
+    a, b = bna.c(), bnb.c()
+    L.check(L.load().yunet_upadd_bwd(_p(za), C.byref(a), _p(zb), C.byref(b), _p(dout), _p(dxa),
+                                     int(acc_a), _p(dxb), int(acc_b), n, h, w, c, _stream()),
+            'yunet_upadd_bwd')
+    return dxa, dxb
+
+
+def bn_update_running(stats, running_mean, running_var, count, momentum=0.1):
+    L.check(L.load().yunet_bn_update_running(_p(stats), _p(running_mean), _p(running_var),
+                                             running_mean.numel(), int(count), float(momentum),
+                                             _stream()), 'yunet_bn_update_running')
+
+
+def bn_param_grad(bstats, dgamma, dbeta, accumulate=False):
+    L.check(L.load().yunet_bn_param_grad(_p(bstats), _p(dgamma), _p(dbeta), dgamma.numel(),
+                                         int(accumulate), _stream()), 'yunet_bn_param_grad')
+
+
+def make_levels(sizes, strides):
+    lv = L.YunetLevels()
+    lv.num_levels = len(sizes)
+    for i, ((h, w), s) in enumerate(zip(sizes, strides)):
+        lv.h[i], lv.w[i], lv.stride[i] = int(h), int(w), int(s)
+    return lv
+
+
+def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.1,
+                  box_eps=1e-6, smooth_point=0.1, kps_beta=1.0 / 9.0):
+    c = L.YunetLossCfg()
+    c.box_loss = {'EIoULoss': L.BOX_EIOU, 'DIoULoss': L.BOX_DIOU}[box_loss]
+    c.w_cls, c.w_box, c.w_obj, c.w_kps = w_cls, w_box, w_obj, w_kps
+    c.box_eps, c.smooth_point, c.kps_beta = box_eps, smooth_point, kps_beta
+    return c
+
+
+def assign(flat, gt_boxes, gt_kps, gt_count, sizes, strides, center_radius=2.5, gt_labels=None,
+           want_labels=False):
+    """flat [N,P,16]; gt_boxes [N,Gmax,4]; gt_kps [N,Gmax,5,3]; gt_count [N] int32.
+    -> gt_inds [N,P] int32, max_overlaps [N,P], img_stats [N,2], labels or None."""
+    _chk_f32(flat, gt_boxes, gt_kps)
+    n, p, _ = flat.shape
+    gmax = gt_boxes.shape[1]
+    dev = flat.device
+    gt_inds = torch.empty(n, p, device=dev, dtype=torch.int32)
+    ovl = torch.empty(n, p, device=dev, dtype=torch.float32)
+    labels = torch.empty(n, p, device=dev, dtype=torch.int32) if want_labels else None
+    img_stats = torch.empty(n, 2, device=dev, dtype=torch.float32)
+    scratch = torch.empty(n, p, 8, device=dev, dtype=torch.float32)
+    lv = make_levels(sizes, strides)
+    L.check(L.load().yunet_assign(_p(flat), _p(gt_boxes), _p(gt_kps), _p(gt_labels), _p(gt_count),
+                                  C.byref(lv), n, p, gmax, float(center_radius), _p(gt_inds),
+                                  _p(labels), _p(ovl), _p(img_stats), _p(scratch), _stream()),
+            'yunet_assign')
+    return gt_inds, ovl, img_stats, labels
+
+
+def loss(flat, gt_inds, ovl, gt_boxes, gt_kps, img_stats, sizes, strides, cfg, inv_world=1.0,
+         norm=None):
+    """-> (losses [4] = cls,bbox,obj,kps ; dflat [N,P,16] ; norm [3])."""
+    n, p, _ = flat.shape
+    gmax = gt_boxes.shape[1]
+    dev = flat.device
+    lib = L.load()
+    if norm is None:
+        norm = torch.empty(4, device=dev, dtype=torch.float32)
+        L.check(lib.yunet_loss_norm(_p(img_stats), n, float(inv_world), _p(norm), _stream()),
+                'yunet_loss_norm')
+    blocks = lib.yunet_loss_blocks(n, p)
+    part = torch.empty(blocks, 4, device=dev, dtype=torch.float32)
+    dflat = torch.empty_like(flat)
+    lv = make_levels(sizes, strides)
+    L.check(lib.yunet_loss(_p(flat), _p(gt_inds), _p(ovl), _p(gt_boxes), _p(gt_kps), C.byref(lv),
+                           C.byref(cfg), _p(norm), n, p, gmax, _p(dflat), _p(part), blocks,
+                           _stream()), 'yunet_loss')
+    losses = torch.empty(4, device=dev, dtype=torch.float32)
+    L.check(lib.yunet_loss_finalize(_p(part), blocks, _p(losses), _stream()), 'yunet_loss_finalize')
+    return losses, dflat, norm
+
+
+def sgd_step(params, grads, buf, lr_dev, momentum, weight_decay, grad_scale=1.0, first=False):
+    L.check(L.load().yunet_sgd_step(_p(params), _p(grads), _p(buf), params.numel(), _p(lr_dev),
+                                    float(momentum), float(weight_decay), float(grad_scale),
+                                    int(first), _stream()), 'yunet_sgd_step')

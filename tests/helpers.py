@@ -1,0 +1,48 @@
+"""Shared test helpers (CPU side): golden loading, tie analysis."""
+import os
+
+import numpy as np
+import torch
+
+import crafted as C
+import yunet_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_loss_inputs(name):
+    g = load_golden(name)
+    flat = torch.from_numpy(g['flat'])
+    gb, gk, cnt = torch.from_numpy(g['gt_boxes']), torch.from_numpy(g['gt_kps']), \
+        torch.from_numpy(g['gt_count'])
+    h, w = int(g['height']), int(g['width'])
+    return g, flat, gb, gk, cnt, h, w
+
+
+def image_near_tie(flat_n, gt_boxes_n, sizes, strides=(8, 16, 32), rel=4e-7):
+    """True if image n's SimOTA decision sits within fp32 transcendental rounding of a tie
+    (k-th vs (k+1)-th cost, conflict argmin, or dynamic-k truncation)."""
+    pri = O.grid_priors(sizes, list(strides))
+    off = torch.cat([pri[:, :2] + pri[:, 2:] * 0.5, pri[:, 2:]], -1)
+    dec = O.bbox_decode(pri, flat_n[:, 1:5])
+    sc = flat_n[:, 0].sigmoid() * flat_n[:, 5].sigmoid()
+    labels = torch.zeros(gt_boxes_n.shape[0], dtype=torch.int64)
+    _, _, _, d = O.simota_assign(sc, off, dec, gt_boxes_n.float(), labels, return_debug=True)
+    cost = torch.sort(d['cost'], dim=0).values
+    for g in range(cost.shape[1]):
+        k = int(d['dynamic_ks'][g])
+        if k < cost.shape[0]:
+            if float((cost[k, g] - cost[k - 1, g]) / cost[k - 1, g].abs()) <= rel:
+                return True
+    K = min(10, d['ious'].shape[0])
+    s = torch.sort(d['ious'], dim=0, descending=True).values[:K].sum(0)
+    if float((s - s.round()).abs().min()) < 1e-5:
+        return True
+    two = torch.sort(d['cost'], dim=1).values
+    if two.shape[1] > 1 and float(((two[:, 1] - two[:, 0]) / two[:, 0].abs()).min()) <= rel:
+        return True
+    return False

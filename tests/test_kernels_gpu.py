@@ -1,0 +1,293 @@
+"""-m gpu: every HIP kernel of libyunet_hip.so, called through the C ABI, against a torch
+fp64 CPU restatement of the same op (floating-point kernels) -- tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def K():
+    import yunet_amd.kernels as k
+    return k
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def stats_of(z_nhwc):
+    z = z_nhwc.double().reshape(-1, z_nhwc.shape[-1])
+    return torch.cat([z.sum(0), (z * z).sum(0)]).contiguous()
+
+
+def bn_ref(x_nchw, gamma, beta, eps=1e-5):
+    """train-mode BN in fp64 -> (bn output, xhat)"""
+    mean = x_nchw.mean(dim=(0, 2, 3), keepdim=True)
+    var = x_nchw.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    xhat = (x_nchw - mean) / torch.sqrt(var + eps)
+    return xhat * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1), xhat
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def mk_unit(cin, cout, g):
+    w_pw = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / (cin + cout)) ** 0.5
+    b_pw = torch.randn(cout, generator=g) * 0.1
+    w_dw = torch.randn(cout, 1, 3, 3, generator=g) * 0.3
+    b_dw = torch.randn(cout, generator=g) * 0.1
+    return w_pw, b_pw, w_dw, b_dw
+
+
+SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5)]
+CHANNELS = [(16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64), (64, 16)]
+
+
+@pytest.mark.parametrize('cin,cout', CHANNELS)
+@pytest.mark.parametrize('with_in_bn', [False, True])
+def test_dp_fwd(cin, cout, with_in_bn):
+    k = K()
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    for (n, h, w) in SHAPES:
+        x = torch.randn(n, cin, h, w, generator=g) * 3 + 1.5
+        w_pw, b_pw, w_dw, b_dw = mk_unit(cin, cout, g)
+        gamma = torch.rand(cin, generator=g) + 0.5
+        beta = torch.randn(cin, generator=g) * 0.2
+        xd = x.double()
+        a = F.relu(bn_ref(xd, gamma.double(), beta.double())[0]) if with_in_bn else xd
+        p = F.conv2d(a, w_pw.double(), b_pw.double())
+        zr = F.conv2d(p, w_dw.double(), b_dw.double(), padding=1, groups=cout)
+        xg = nhwc(x).to(DEV)
+        in_bn = None
+        if with_in_bn:
+            in_bn = k.BN(stats_of(xg).to(DEV), gamma.to(DEV), beta.to(DEV), n * h * w)
+        out_stats = torch.zeros(2 * cout, dtype=torch.float64, device=DEV)
+        out_bn = k.BN(out_stats, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV),
+                      n * h * w) if cout != 16 or cin != 64 else None
+        z = k.dp_fwd(xg, w_pw.to(DEV).view(cout, cin).contiguous(), b_pw.to(DEV),
+                     w_dw.to(DEV).view(cout, 9).contiguous(), b_dw.to(DEV), in_bn, out_bn)
+        torch.cuda.synchronize()
+        assert rel_err(nchw(z.cpu()), zr) < 2e-5, (n, h, w)
+        if out_bn is not None:
+            sr = stats_of(nhwc(zr))
+            assert rel_err(out_stats, sr) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout', CHANNELS)
+@pytest.mark.parametrize('mode', ['bn_bn', 'id_bn', 'bn_nobn'])
+def test_dp_bwd(cin, cout, mode):
+    """dx / dW1 / db1 / dW2 / db2 and the producer's BN-backward sums vs fp64 autograd."""
+    k = K()
+    g = torch.Generator().manual_seed(7 + cin * 100 + cout)
+    in_bn_on = mode.startswith('bn')
+    out_bn_on = mode.endswith('_bn')
+    for (n, h, w) in SHAPES[:3]:
+        x = (torch.randn(n, cin, h, w, generator=g) * 2 + 0.5).double()
+        w_pw, b_pw, w_dw, b_dw = [t.double().requires_grad_(True) for t in mk_unit(cin, cout, g)]
+        gi, bi = (torch.rand(cin, generator=g) + 0.5).double(), (torch.randn(cin, generator=g) * .2).double()
+        go, bo = (torch.rand(cout, generator=g) + 0.5).double(), (torch.randn(cout, generator=g) * .2).double()
+        r = torch.randn(n, cout, h, w, generator=g).double()
+        if in_bn_on:
+            b_in, xhat_in = bn_ref(x, gi, bi)
+            b_in = b_in.detach().requires_grad_(True)
+            a = F.relu(b_in)
+        else:
+            b_in = x.clone().requires_grad_(True)
+            a = b_in
+        z = F.conv2d(F.conv2d(a, w_pw, b_pw), w_dw, b_dw, padding=1, groups=cout)
+        if out_bn_on:
+            zb, xhat_out = bn_ref(z, go, bo)
+            zb.retain_grad()
+            y = F.relu(zb)
+            (y * r).sum().backward()
+            dy_ref = zb.grad           # grad wrt BN output, ReLU mask applied
+        else:
+            scale = torch.rand(cout, generator=g).double() + 0.5
+            (z * r * scale.view(1, -1, 1, 1)).sum().backward()
+            dy_ref = r
+        # ---- kernel
+        xg = nhwc(x.float()).to(DEV)
+        in_bn = out_bn = None
+        if in_bn_on:
+            in_bn = k.BN(stats_of(xg), gi.float().to(DEV), bi.float().to(DEV), n * h * w,
+                         bstats=torch.zeros(2 * cin, dtype=torch.float64, device=DEV))
+        zg = nhwc(z.detach().float()).to(DEV)
+        dyg = nhwc(dy_ref.float()).to(DEV)
+        dy_scale = None
+        if out_bn_on:
+            bst = torch.cat([dy_ref.sum(dim=(0, 2, 3)), (dy_ref * xhat_out.detach()).sum(dim=(0, 2, 3))])
+            out_bn = k.BN(stats_of(zg), go.float().to(DEV), bo.float().to(DEV), n * h * w,
+                          bstats=bst.to(DEV).contiguous())
+        else:
+            dy_scale = scale.float().to(DEV)
+        dx, dw1, db1, dw2, db2 = k.dp_bwd(
+            xg, w_pw.detach().float().to(DEV).view(cout, cin).contiguous(), b_pw.detach().float().to(DEV),
+            w_dw.detach().float().to(DEV).view(cout, 9).contiguous(), b_dw.detach().float().to(DEV),
+            zg, dyg, in_bn, out_bn, dy_scale=dy_scale)
+        torch.cuda.synchronize()
+        tol = 5e-5
+        assert rel_err(nchw(dx.cpu()), b_in.grad) < tol, ('dx', n, h, w)
+        assert rel_err(dw1, w_pw.grad) < tol, ('dw1', n, h, w)
+        assert rel_err(db1, b_pw.grad) < tol, ('db1', n, h, w)
+        assert rel_err(dw2, w_dw.grad) < tol, ('dw2', n, h, w)
+        if not out_bn_on:   # with BN the dw-bias gradient is identically zero (noise only)
+            assert rel_err(db2, b_dw.grad) < tol, ('db2', n, h, w)
+        else:
+            assert float(db2.abs().max()) < 1e-3 * float(dy_ref.abs().sum())
+        if in_bn_on:
+            ref_b = torch.cat([b_in.grad.sum(dim=(0, 2, 3)), (b_in.grad * xhat_in).sum(dim=(0, 2, 3))])
+            assert rel_err(in_bn.bstats, ref_b) < tol
+
+
+def test_dp_bwd_accumulate():
+    k = K()
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 2, 12, 20, 16, 16
+    x = nhwc(torch.randn(n, cin, h, w, generator=g)).to(DEV)
+    w_pw, b_pw, w_dw, b_dw = [t.to(DEV) for t in mk_unit(cin, cout, g)]
+    z = torch.randn(n, h, w, cout, generator=g).to(DEV)
+    dy = torch.randn(n, h, w, cout, generator=g).to(DEV)
+    args = (x, w_pw.view(cout, cin).contiguous(), b_pw, w_dw.view(cout, 9).contiguous(), b_dw, z, dy)
+    dx0 = k.dp_bwd(*args)[0]
+    base = torch.randn(n, h, w, cin, generator=g).to(DEV)
+    dx1 = base.clone()
+    k.dp_bwd(*args, dx=dx1, accumulate_dx=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(dx1, base + dx0, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 32, 32), (3, 64, 96), (1, 20, 36)])
+def test_stem_fwd_bwd(n, h, w):
+    k = K()
+    g = torch.Generator().manual_seed(h)
+    img = torch.rand(n, 3, h, w, generator=g) * 255
+    wt = (torch.randn(16, 3, 3, 3, generator=g) * 0.05).double().requires_grad_(True)
+    b = (torch.randn(16, generator=g) * 0.1).double().requires_grad_(True)
+    gamma, beta = (torch.rand(16, generator=g) + 0.5).double(), torch.randn(16, generator=g).double() * 0.2
+    z = F.conv2d(img.double(), wt, b, stride=2, padding=1)
+    zb, xhat = bn_ref(z, gamma, beta)
+    zb.retain_grad()
+    r = torch.randn(z.shape, generator=g).double()
+    (F.relu(zb) * r).sum().backward()
+    stats = torch.zeros(32, dtype=torch.float64, device=DEV)
+    zg = k.stem_fwd(img.to(DEV), wt.detach().float().to(DEV), b.detach().float().to(DEV), stats)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(zg.cpu()), z.detach()) < 2e-5
+    assert rel_err(stats, stats_of(nhwc(z.detach()))) < 2e-5
+    dy = zb.grad
+    bst = torch.cat([dy.sum(dim=(0, 2, 3)), (dy * xhat.detach()).sum(dim=(0, 2, 3))]).to(DEV)
+    bn = k.BN(stats, gamma.float().to(DEV), beta.float().to(DEV), n * (h // 2) * (w // 2), bstats=bst)
+    dw, db = k.stem_bwd(img.to(DEV), zg, nhwc(dy.float()).to(DEV), bn)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wt.grad) < 1e-4
+    assert float(db.abs().max()) < 1e-3 * float(dy.abs().sum())
+
+
+@pytest.mark.parametrize('c', [16, 32, 64])
+def test_pool_fwd_bwd(c):
+    k = K()
+    g = torch.Generator().manual_seed(c)
+    n, h, w = 3, 12, 20
+    z = (torch.randn(n, c, h, w, generator=g) * 2).double()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).double(), torch.randn(c, generator=g).double() * .3
+    zb, xhat = bn_ref(z, gamma, beta)
+    zb = zb.detach().requires_grad_(True)
+    out = F.max_pool2d(F.relu(zb), 2)
+    r = torch.randn(out.shape, generator=g).double()
+    (out * r).sum().backward()
+    zg = nhwc(z.float()).to(DEV)
+    bn = k.BN(stats_of(zg), gamma.float().to(DEV), beta.float().to(DEV), n * h * w,
+              bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
+    og = k.pool_fwd(zg, bn)
+    dx = k.pool_bwd(zg, bn, nhwc(r.float()).to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(og.cpu()), out.detach()) < 2e-5
+    assert rel_err(nchw(dx.cpu()), zb.grad) < 2e-5
+    ref_b = torch.cat([zb.grad.sum(dim=(0, 2, 3)), (zb.grad * xhat).sum(dim=(0, 2, 3))])
+    assert rel_err(bn.bstats, ref_b) < 5e-5
+
+
+def test_upadd_fwd_bwd():
+    k = K()
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 2, 12, 20, 64
+    za = (torch.randn(n, c, h, w, generator=g) * 2).double()
+    zb_ = (torch.randn(n, c, h // 2, w // 2, generator=g) * 2).double()
+    ga, ba = (torch.rand(c, generator=g) + 0.5).double(), torch.randn(c, generator=g).double() * .3
+    gb, bb = (torch.rand(c, generator=g) + 0.5).double(), torch.randn(c, generator=g).double() * .3
+    ya, xha = bn_ref(za, ga, ba)
+    yb, xhb = bn_ref(zb_, gb, bb)
+    ya = ya.detach().requires_grad_(True)
+    yb = yb.detach().requires_grad_(True)
+    out = F.relu(ya) + F.interpolate(F.relu(yb), scale_factor=2., mode='nearest')
+    r = torch.randn(out.shape, generator=g).double()
+    (out * r).sum().backward()
+    zag, zbg = nhwc(za.float()).to(DEV), nhwc(zb_.float()).to(DEV)
+    bna = k.BN(stats_of(zag), ga.float().to(DEV), ba.float().to(DEV), n * h * w,
+               bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
+    bnb = k.BN(stats_of(zbg), gb.float().to(DEV), bb.float().to(DEV), n * h * w // 4,
+               bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
+    og = k.upadd_fwd(zag, bna, zbg, bnb)
+    dxa, dxb = k.upadd_bwd(zag, bna, zbg, bnb, nhwc(r.float()).to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(og.cpu()), out.detach()) < 2e-5
+    assert rel_err(nchw(dxa.cpu()), ya.grad) < 2e-5
+    assert rel_err(nchw(dxb.cpu()), yb.grad) < 2e-5
+    assert rel_err(bna.bstats, torch.cat([ya.grad.sum(dim=(0, 2, 3)), (ya.grad * xha).sum(dim=(0, 2, 3))])) < 5e-5
+    assert rel_err(bnb.bstats, torch.cat([yb.grad.sum(dim=(0, 2, 3)), (yb.grad * xhb).sum(dim=(0, 2, 3))])) < 5e-5
+
+
+def test_bn_running_and_param_grad():
+    k = K()
+    g = torch.Generator().manual_seed(5)
+    c, cnt = 64, 777
+    x = torch.randn(cnt, c, generator=g).double() * 3 + 2
+    stats = torch.cat([x.sum(0), (x * x).sum(0)]).to(DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    k.bn_update_running(stats, rm, rv, cnt)
+    torch.cuda.synchronize()
+    assert rel_err(rm, 0.1 * x.mean(0)) < 1e-5
+    assert rel_err(rv, 0.9 + 0.1 * x.var(0, unbiased=True)) < 1e-5
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    k.bn_param_grad(stats, dg, db)
+    torch.cuda.synchronize()
+    assert rel_err(db, x.sum(0)) < 1e-6 and rel_err(dg, (x * x).sum(0)) < 1e-6
+
+
+def test_sgd_matches_torch():
+    k = K()
+    g = torch.Generator().manual_seed(9)
+    n = 75856
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    p = p0.clone().to(DEV)
+    buf = torch.zeros(n, device=DEV)
+    lr = torch.tensor([0.01], device=DEV)
+    for it in range(3):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        k.sgd_step(p, gr.to(DEV), buf, lr, 0.9, 5e-4, first=(it == 0))
+    torch.cuda.synchronize()
+    assert rel_err(p, ref.detach()) < 1e-6
+
+
+def test_reduce_partials():
+    k = K()
+    g = torch.Generator().manual_seed(1)
+    part = torch.randn(1000, 4816, generator=g).to(DEV)
+    out = torch.zeros(4816, device=DEV)
+    k.reduce_partials(part, out)
+    torch.cuda.synchronize()
+    assert rel_err(out, part.double().sum(0)) < 1e-5
