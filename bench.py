@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec of the YuNet hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of YuNet_n on a 256-image 320x320 synthetic
+WIDER-Face-shaped batch per GPU (BASELINE.json configs[1]): the reference's per-iteration
+sequence model.train_step -> zero_grad -> loss.backward -> optimizer.step
+(forward + SimOTA + 4 losses + backward + gradient all-reduce + SGD), fp32, inputs already
+resident in HBM.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (N=1 only):
+  roofline     -- the kernel with the largest share of the step, timed per launch with
+                  events on the launch stream; achieved = algorithmic bytes / duration
+  cpu_baseline -- the CPU oracle (a port of the reference step, oracle/yunet_oracle.py) timed
+                  on this host's cores over a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+KIND, H, W, BATCH = 'n', 320, 320, 256
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=BATCH, help='images per GPU (default 256)')
+    p.add_argument('--size', type=int, default=H)
+    p.add_argument('--kind', default=KIND, choices=['n', 's'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    return p.parse_args()
+
+
+# ----------------------------------------------------------------- algorithmic byte model
+def op_bytes(op, L):
+    """Algorithmic HBM bytes of one launch (SURVEY.md 8d 'unit-boundary traffic', fp32):
+    forward unit = in + out, backward unit = 2*in + out; weights negligible."""
+    oc = op.opcode
+    if oc in (L.OP_DP_FWD, L.OP_DP_BWD):
+        d = op.dp
+        px = d.N * d.H * d.W
+        i, o = px * d.cin * 4, px * d.cout * 4
+        return i + o if oc == L.OP_DP_FWD else 2 * i + o
+    if oc in (L.OP_STEM_FWD, L.OP_STEM_BWD):
+        n, h, w = op.i[0], op.i[1], op.i[2]
+        i, o = n * 3 * h * w * 4, n * (h // 2) * (w // 2) * 16 * 4
+        return i + o if oc == L.OP_STEM_FWD else 2 * i + o
+    if oc in (L.OP_POOL_FWD, L.OP_POOL_BWD):
+        n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
+        i, o = n * h * w * c * 4, n * h * w * c
+        return i + o if oc == L.OP_POOL_FWD else 2 * i + o
+    if oc in (L.OP_UPADD_FWD, L.OP_UPADD_BWD):
+        n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
+        a, b = n * h * w * c * 4, n * h * w * c
+        return (a + b + a) if oc == L.OP_UPADD_FWD else 2 * (a + b) + a
+    if oc == L.OP_LOSS:
+        return op.i[0] * op.i[1] * 16 * 4 * 2
+    if oc == L.OP_ASSIGN:
+        return op.i[0] * op.i[1] * 16 * 4
+    return 0
+
+
+def op_name(op, L):
+    names = {L.OP_STEM_FWD: 'stem_fwd_kernel', L.OP_STEM_BWD: 'stem_bwd_kernel',
+             L.OP_POOL_FWD: 'pool_fwd_kernel', L.OP_POOL_BWD: 'pool_bwd_kernel',
+             L.OP_UPADD_FWD: 'upadd_fwd_kernel', L.OP_UPADD_BWD: 'upadd_bwd_kernel',
+             L.OP_ASSIGN: 'assign_kernel', L.OP_LOSS: 'loss_kernel',
+             L.OP_LOSS_NORM: 'loss_norm_kernel', L.OP_LOSS_FINALIZE: 'loss_finalize_kernel',
+             L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
+             L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset'}
+    if op.opcode == L.OP_DP_FWD:
+        return f'dp_fwd_kernel<{op.dp.cin},{op.dp.cout},8,16>'
+    if op.opcode == L.OP_DP_BWD:
+        return f'dp_bwd_kernel<{op.dp.cin},{op.dp.cout},8,16>'
+    return names.get(op.opcode, f'op{op.opcode}')
+
+
+def profile_ops(eng, reps=3):
+    """Time every launch of the step individually: events on the launch stream around
+    single-op yunet_exec calls.  Returns {kernel name: dict(launches, ms, bytes)} per step."""
+    import yunet_amd._lib as L
+    plan = eng.plan
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    agg = {}
+    for rep in range(reps + 1):
+        for arr in (plan.c_fwd_a, plan.c_fwd_b, plan.c_bwd):
+            evs = []
+            for k in range(len(arr)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = eng.lib.yunet_exec(C.cast(C.byref(arr, k * C.sizeof(L.YunetOp)),
+                                               C.POINTER(L.YunetOp)), 1, sptr)
+                e1.record(stream)
+                assert rc == 0, rc
+                evs.append((k, e0, e1))
+            torch.cuda.synchronize()
+            if rep == 0:
+                continue            # warm-up pass
+            for k, e0, e1 in evs:
+                op = arr[k]
+                a = agg.setdefault(op_name(op, L), dict(launches=0, ms=0.0, bytes=0))
+                a['launches'] += 1
+                a['ms'] += e0.elapsed_time(e1)
+                a['bytes'] += op_bytes(op, L)
+    for a in agg.values():
+        a['launches'] //= reps
+        a['ms'] /= reps
+        a['bytes'] //= reps
+    return agg
+
+
+def cpu_baseline(kind, size, seed=1234):
+    """The CPU oracle's full training step on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import yunet_oracle as O
+    import yunet_amd.synthetic as S
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    arch = O.yunet_arch(kind)
+    sd = O.init_state(arch, seed=0)
+    opt = O.SGD(lr=1e-5)
+    bs = 32
+    b = S.make_batch(bs, size, size, seed)
+    O.train_step(b, sd, arch, opt)          # warm-up
+    t0 = time.time()
+    iters = 0
+    while iters < 3 or (time.time() - t0 < 10.0 and iters < 20):
+        O.train_step(b, sd, arch, opt)
+        iters += 1
+    dt = time.time() - t0
+    return dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
+                sample=f'oracle/yunet_oracle.py train_step, YuNet_{kind} {size}x{size} bs {bs}, '
+                       f'{iters} iters after 1 warm-up, torch CPU fp32, {cores} threads')
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 '
+                         '--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import yunet_amd
+    import yunet_amd.synthetic as S
+    from yunet_amd.optim import FusedSGD
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', f'yunet_{a.kind}.py'))
+    torch.manual_seed(0)
+    model = yunet_amd.build_detector(cfg.model).to(dev)
+    model.train()
+    wrapped = YuNetDistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    opt = FusedSGD(model, lr=cfg.optimizer['lr'] * 0.001, momentum=cfg.optimizer['momentum'],
+                   weight_decay=cfg.optimizer['weight_decay'])   # lr at warm-up iteration 0
+
+    # synthetic batches, resident in HBM before the timed region
+    pool = [S.to_device(S.make_batch(a.batch, a.size, a.size, S.batch_seed(rank, i)), dev)
+            for i in range(2)]
+
+    def step(i):
+        out = wrapped.train_step(pool[i % len(pool)], opt)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+        return out
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_loss = float(out['log_vars']['loss'])
+
+    res = None
+    if rank == 0:
+        res = {
+            'metric': 'training images/sec, YuNet_n 320x320 bs=256/GPU' if (a.kind, a.size, a.batch) == (KIND, H, BATCH)
+            else f'training images/sec, YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU',
+            'value': round(world * a.batch * a.steps / dt, 1), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU full training '
+                                   'step (fwd + SimOTA + losses + bwd + grad all-reduce + SGD), '
+                                   'synthetic WIDER-Face-shaped batches, fp32',
+                       'parallelism': f'dp{world}', 'global_batch': world * a.batch},
+            'final_loss': round(last_loss, 4),
+        }
+    if rank == 0 and world == 1 and not a.no_roofline:
+        agg = profile_ops(model.engine)
+        tot = sum(v['ms'] for v in agg.values())
+        name, top = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        per_launch_ms = top['ms'] / top['launches']
+        achieved = top['bytes'] / top['launches'] / (per_launch_ms * 1e-3) / 1e9
+        res['roofline'] = {
+            'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': name,
+            'launches_per_step': top['launches'], 'avg_launch_ms': round(per_launch_ms, 4),
+            'algorithmic_bytes_per_launch': top['bytes'] // top['launches'],
+            'share_of_step': round(top['ms'] / tot, 3),
+            'step_algorithmic_GBs': round(sum(v['bytes'] for v in agg.values()) /
+                                          (1e-3 * 1000.0 * dt / a.steps) / 1e9, 1),
+        }
+        res['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 4),
+                              'GBs': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(a.kind, a.size)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -143,6 +143,15 @@ int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
                  int32_t* labels, float* max_overlaps, float* img_stats, float* scratch,
                  void* stream);
 
+/* Same kernel driven through SimOTAAssigner.assign()'s own signature
+ * (sim_ota_assigner.py:38-93): pred_scores [N,P] = sigmoid(cls)*sigmoid(obj) and
+ * decoded_bboxes [N,P,4] are given instead of being derived from `flat` (flat may be NULL). */
+int yunet_assign_ex(const float* flat, const float* pre_scores, const float* pre_boxes,
+                    const float* gt_boxes, const float* gt_kps, const int32_t* gt_labels,
+                    const int32_t* gt_count, const YunetLevels* lv, int N, int P, int Gmax,
+                    float center_radius, int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                    float* img_stats, float* scratch, void* stream);
+
 /* norm[0] = sum_n num_pos / world (the rank-local term of reduce_mean, yunet_head.py:493-497,
  * to be all-reduced by the caller when world > 1), norm[1] = sum_n kps weight. */
 int yunet_loss_norm(const float* img_stats, int N, float inv_world, float* norm, void* stream);

@@ -77,6 +77,8 @@ _SIGNATURES = {
                                         C.c_void_p]),
     'yunet_assign': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +
                      [C.c_float] + [C.c_void_p] * 6),
+    'yunet_assign_ex': (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +
+                        [C.c_float] + [C.c_void_p] * 6),
     'yunet_loss_norm': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'yunet_loss': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels), C.POINTER(YunetLossCfg),
                                                 C.c_void_p] + [C.c_int] * 3 +

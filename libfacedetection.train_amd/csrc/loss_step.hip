@@ -126,7 +126,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
     const float* __restrict__ gt_kps, const int32_t* __restrict__ gt_labels,
     const int32_t* __restrict__ gt_count, Levels L, int P, int Gmax, float radius,
     int32_t* __restrict__ gt_inds, int32_t* __restrict__ labels, float* __restrict__ max_overlaps,
-    float* __restrict__ img_stats, VRec* __restrict__ scratch_all) {
+    float* __restrict__ img_stats, VRec* __restrict__ scratch_all,
+    const float* __restrict__ pre_scores, const float* __restrict__ pre_boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: gt[Gmax] | cnt[P] int | vidx[P] u16 | mg[P] u16 | misc
     GT* s_gt = reinterpret_cast<GT*>(smem);
@@ -170,7 +171,13 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
             gt_inds[(size_t)n * P + p] = 0;
             max_overlaps[(size_t)n * P + p] = -INF_COST;
             if (labels) labels[(size_t)n * P + p] = -1;
-            if (valid) {
+            if (valid && pre_scores) {
+                // stand-alone SimOTAAssigner.assign(): scores and decoded boxes are inputs
+                const float4 bx = *reinterpret_cast<const float4*>(pre_boxes + ((size_t)n * P + p) * 4);
+                rec.x1 = bx.x; rec.y1 = bx.y; rec.x2 = bx.z; rec.y2 = bx.w;
+                rec.cls_cost = -fmaxf(logf(sqrtf(pre_scores[(size_t)n * P + p])), -100.0f);
+                rec.cx = cx; rec.cy = cy; rec.s = s;
+            } else if (valid) {
                 const float4 a = *reinterpret_cast<const float4*>(fl + (size_t)p * 16);
                 const float2 b = *reinterpret_cast<const float2*>(fl + (size_t)p * 16 + 4);
                 // a = cls, dx, dy, dw ; b = dh, obj
@@ -569,11 +576,12 @@ extern "C" int yunet_loss_blocks(int N, int P) {
     return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
 }
 
-extern "C" int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
-                            const int32_t* gt_labels, const int32_t* gt_count,
-                            const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
-                            int32_t* gt_inds, int32_t* labels, float* max_overlaps,
-                            float* img_stats, float* scratch, void* stream) {
+extern "C" int yunet_assign_ex(const float* flat, const float* pre_scores, const float* pre_boxes,
+                               const float* gt_boxes, const float* gt_kps,
+                               const int32_t* gt_labels, const int32_t* gt_count,
+                               const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
+                               int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                               float* img_stats, float* scratch, void* stream) {
     if (!lv || lv->num_levels < 1 || lv->num_levels > YUNET_MAX_LEVELS || P > 65535 || N < 1 ||
         Gmax < 1)
         return YUNET_EINVAL;
@@ -584,8 +592,19 @@ extern "C" int yunet_assign(const float* flat, const float* gt_boxes, const floa
     if (lds > 150 * 1024) return YUNET_EINVAL;
     hipLaunchKernelGGL(assign_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, (hipStream_t)stream, flat,
                        gt_boxes, gt_kps, gt_labels, gt_count, L, P, Gmax, center_radius, gt_inds,
-                       labels, max_overlaps, img_stats, reinterpret_cast<VRec*>(scratch));
+                       labels, max_overlaps, img_stats, reinterpret_cast<VRec*>(scratch), pre_scores,
+                       pre_boxes);
     return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
+                            const int32_t* gt_labels, const int32_t* gt_count,
+                            const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
+                            int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                            float* img_stats, float* scratch, void* stream) {
+    return yunet_assign_ex(flat, nullptr, nullptr, gt_boxes, gt_kps, gt_labels, gt_count, lv, N, P,
+                           Gmax, center_radius, gt_inds, labels, max_overlaps, img_stats, scratch,
+                           stream);
 }
 
 extern "C" int yunet_loss_norm(const float* img_stats, int N, float inv_world, float* norm,

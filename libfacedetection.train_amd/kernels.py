@@ -215,24 +215,31 @@ def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.
 
 
 def assign(flat, gt_boxes, gt_kps, gt_count, sizes, strides, center_radius=2.5, gt_labels=None,
-           want_labels=False):
+           want_labels=False, pre_scores=None, pre_boxes=None):
     """flat [N,P,16]; gt_boxes [N,Gmax,4]; gt_kps [N,Gmax,5,3]; gt_count [N] int32.
     -> gt_inds [N,P] int32, max_overlaps [N,P], img_stats [N,2], labels or None."""
-    _chk_f32(flat, gt_boxes, gt_kps)
-    n, p, _ = flat.shape
+    _chk_f32(flat, gt_boxes, gt_kps, pre_scores, pre_boxes)
+    n, p = (flat.shape[0], flat.shape[1]) if flat is not None else pre_scores.shape
     gmax = gt_boxes.shape[1]
-    dev = flat.device
+    dev = gt_boxes.device
     gt_inds = torch.empty(n, p, device=dev, dtype=torch.int32)
     ovl = torch.empty(n, p, device=dev, dtype=torch.float32)
     labels = torch.empty(n, p, device=dev, dtype=torch.int32) if want_labels else None
     img_stats = torch.empty(n, 2, device=dev, dtype=torch.float32)
     scratch = torch.empty(n, p, 8, device=dev, dtype=torch.float32)
     lv = make_levels(sizes, strides)
-    L.check(L.load().yunet_assign(_p(flat), _p(gt_boxes), _p(gt_kps), _p(gt_labels), _p(gt_count),
-                                  C.byref(lv), n, p, gmax, float(center_radius), _p(gt_inds),
-                                  _p(labels), _p(ovl), _p(img_stats), _p(scratch), _stream()),
-            'yunet_assign')
+    L.check(L.load().yunet_assign_ex(_p(flat), _p(pre_scores), _p(pre_boxes), _p(gt_boxes),
+                                     _p(gt_kps), _p(gt_labels), _p(gt_count), C.byref(lv), n, p,
+                                     gmax, float(center_radius), _p(gt_inds), _p(labels), _p(ovl),
+                                     _p(img_stats), _p(scratch), _stream()), 'yunet_assign')
     return gt_inds, ovl, img_stats, labels
+
+
+def loss_norm(img_stats, inv_world=1.0):
+    norm = torch.empty(4, device=img_stats.device, dtype=torch.float32)
+    L.check(L.load().yunet_loss_norm(_p(img_stats), img_stats.shape[0], float(inv_world), _p(norm),
+                                     _stream()), 'yunet_loss_norm')
+    return norm
 
 
 def loss(flat, gt_inds, ovl, gt_boxes, gt_kps, img_stats, sizes, strides, cfg, inv_world=1.0,
@@ -243,9 +250,7 @@ def loss(flat, gt_inds, ovl, gt_boxes, gt_kps, img_stats, sizes, strides, cfg, i
     dev = flat.device
     lib = L.load()
     if norm is None:
-        norm = torch.empty(4, device=dev, dtype=torch.float32)
-        L.check(lib.yunet_loss_norm(_p(img_stats), n, float(inv_world), _p(norm), _stream()),
-                'yunet_loss_norm')
+        norm = loss_norm(img_stats, inv_world)
     blocks = lib.yunet_loss_blocks(n, p)
     part = torch.empty(blocks, 4, device=dev, dtype=torch.float32)
     dflat = torch.empty_like(flat)

@@ -1,0 +1,80 @@
+"""Data parallelism: one process per GPU, RCCL over xGMI through torch.distributed.
+
+The reference wraps the detector in mmcv's MMDistributedDataParallel (a torch DDP subclass,
+mmdet/apis/train.py:152-163, mmdet/utils/util_distribution.py:5-59; backend 'nccl',
+configs/yunet_n.py:18).  Per step that is one ~300 KB gradient bucket plus six scalar
+collectives.  Here the gradient already lives in ONE flat buffer, so the
+exchange is exactly one all-reduce of 75,856 / 54,608 floats issued on the backward stream
+right after the last backward kernel, plus one 4-byte all-reduce for num_pos; the logging
+scalars travel as a single 5-float message.  BatchNorm statistics stay per-rank
+(no SyncBN; broadcast_buffers=False in the reference).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def init_dist(launcher='pytorch', backend='nccl', **kwargs):
+    """tools/train.py:163-170 -> mmcv init_dist.  'nccl' is RCCL on ROCm."""
+    if dist.is_initialized():
+        return
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    if backend == 'nccl' and torch.cuda.is_available():
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class YuNetDistributedDataParallel(nn.Module):
+    """Drop-in for MMDistributedDataParallel on this path: `train_step` scatters the batch
+    to the local device and calls the module; gradient averaging is done by the module's
+    engine (one flat all-reduce) instead of DDP's autograd-hook reducer."""
+
+    def __init__(self, module, device_ids=None, broadcast_buffers=False,
+                 find_unused_parameters=False, process_group=None):
+        super().__init__()
+        self.module = module
+        self.device = torch.device('cuda', device_ids[0]) if device_ids else None
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        module.set_data_parallel(world, process_group)
+        if world > 1:   # start from identical weights, like DDP's initial broadcast
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def _to_device(self, data):
+        if self.device is None:
+            return data
+        out = {}
+        for k, v in data.items():
+            if torch.is_tensor(v):
+                out[k] = v.to(self.device, non_blocking=True)
+            elif isinstance(v, (list, tuple)) and v and torch.is_tensor(v[0]):
+                out[k] = [t.to(self.device, non_blocking=True) for t in v]
+            else:
+                out[k] = v
+        return out
+
+    def train_step(self, data, optimizer):
+        return self.module.train_step(self._to_device(data), optimizer)
+
+    def val_step(self, data, optimizer):
+        return self.module.val_step(self._to_device(data), optimizer)
+
+
+def build_ddp(model, device='cuda', *args, **kwargs):
+    """mmdet/utils/util_distribution.py:36-59."""
+    return YuNetDistributedDataParallel(model, *args, **kwargs)

@@ -1,0 +1,179 @@
+"""YuNet_Head with the reference's constructor / method signatures
+(mmdet/models/dense_heads/yunet_head.py:16-604).
+
+`loss()` flattens the NCHW maps exactly like the reference (:456-477) and then runs the
+whole loss step -- priors, decode, SimOTA, targets, four losses and their gradients -- in
+the fused HIP kernels (`yunet_assign`, `yunet_loss`).  Inside `YuNet.forward_train` the
+detector's engine skips even the flattening: the fused head kernels write [N,P,16]
+directly.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .builder import HEADS, build_assigner, build_loss, build_prior_generator, build_sampler
+from .registry import ConfigDict
+from .yunet_layer import ConvDPUnit, yunet_init_weights
+
+
+def pad_gt(gt_bboxes, gt_kpss, device):
+    """ragged lists -> padded [N,Gmax,4], [N,Gmax,5,3], counts [N] int32 (on `device`)."""
+    n = len(gt_bboxes)
+    counts = [int(b.shape[0]) for b in gt_bboxes]
+    gmax = max(counts + [1])
+    gb = torch.zeros(n, gmax, 4, device=device)
+    gk = torch.zeros(n, gmax, 5, 3, device=device)
+    for i, c in enumerate(counts):
+        if c:
+            gb[i, :c] = gt_bboxes[i].to(device, torch.float32)
+            gk[i, :c] = gt_kpss[i].to(device, torch.float32)
+    return gb, gk, torch.tensor(counts, dtype=torch.int32, device=device)
+
+
+class _LossStep(torch.autograd.Function):
+    """flat [N,P,16] -> (loss_cls, loss_bbox, loss_obj, loss_kps); the kernel already produced
+    d(loss_i)/d(flat) for the loss that owns each channel."""
+
+    @staticmethod
+    def forward(ctx, flat, gb, gk, cnt, sizes, strides, cfg, radius, world, group):
+        gi, ovl, img_stats, _ = K.assign(flat, gb, gk, cnt, sizes, strides, radius)
+        norm = None
+        if world > 1:
+            # reduce_mean(num_pos) (yunet_head.py:493-497): norm[0] = local/world, SUM over ranks
+            norm = K.loss_norm(img_stats, 1.0 / world)
+            torch.distributed.all_reduce(norm[0:1], group=group)
+        losses, dflat, norm = K.loss(flat, gi, ovl, gb, gk, img_stats, sizes, strides, cfg,
+                                     1.0 / world, norm)
+        ctx.save_for_backward(dflat)
+        ctx.mark_non_differentiable(gi)
+        return losses[0], losses[1], losses[2], losses[3], gi
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, g_obj, g_kps, _gi):
+        (dflat,) = ctx.saved_tensors
+        z = dflat.new_zeros(())
+        gs = [g if g is not None else z for g in (g_cls, g_box, g_obj, g_kps)]
+        scale = torch.stack([gs[0]] + [gs[1]] * 4 + [gs[2]] + [gs[3]] * 10)
+        return (dflat * scale,) + (None,) * 9
+
+
+@HEADS.register_module()
+class YuNet_Head(nn.Module):
+    def __init__(self, num_classes, in_channels, feat_channels=256, shared_stacked_convs=2,
+                 stacked_convs=2,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='sum',
+                               loss_weight=1.0),
+                 loss_bbox=dict(type='EIoULoss', reduction='sum', loss_weight=5.0),
+                 use_kps=False, kps_num=5, loss_kps=None, prior_generator=None, train_cfg=None,
+                 test_cfg=None,
+                 loss_obj=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='sum',
+                               loss_weight=1.0)):
+        super().__init__()
+        if num_classes != 1 or not use_kps or kps_num != 5:
+            raise NotImplementedError('the fused head kernels implement the shipped face '
+                                      'configuration: 1 class, 5 landmarks')
+        if stacked_convs != 0:
+            raise NotImplementedError('stacked_convs > 0 is not used by configs/yunet_{n,s}.py')
+        self.num_classes = self.cls_out_channels = num_classes
+        self.NK = kps_num
+        self.in_channels, self.feat_channels = in_channels, feat_channels
+        self.stacked_convs, self.shared_stack_convs = stacked_convs, shared_stacked_convs
+        self.use_sigmoid_cls, self.use_kps = True, use_kps
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.loss_kps = build_loss(loss_kps)
+        self.loss_obj = build_loss(loss_obj)
+        self.prior_generator = build_prior_generator(prior_generator)
+        self.strides = [s[0] for s in self.prior_generator.strides]
+        self.strides_num = len(self.strides)
+        self.test_cfg, self.train_cfg = test_cfg, train_cfg
+        self.sampling = False
+        self.assigner = None
+        if self.train_cfg:
+            self.assigner = build_assigner(ConfigDict.wrap(self.train_cfg).assigner)
+            self.sampler = build_sampler(dict(type='PseudoSampler'), context=self)
+        self.fp16_enabled = False
+        self._init_layers()
+        self.init_weights()
+
+    def _init_layers(self):
+        if self.shared_stack_convs > 0:
+            self.multi_level_share_convs = nn.ModuleList()
+        self.multi_level_cls = nn.ModuleList()
+        self.multi_level_bbox = nn.ModuleList()
+        self.multi_level_obj = nn.ModuleList()
+        self.multi_level_kps = nn.ModuleList()
+        for _ in self.strides:
+            if self.shared_stack_convs > 0:
+                convs = [ConvDPUnit(self.in_channels if i == 0 else self.feat_channels,
+                                    self.feat_channels) for i in range(self.shared_stack_convs)]
+                self.multi_level_share_convs.append(nn.Sequential(*convs))
+            chn = self.in_channels if self.shared_stack_convs == 0 else self.feat_channels
+            self.multi_level_cls.append(ConvDPUnit(chn, self.num_classes, False))
+            self.multi_level_bbox.append(ConvDPUnit(chn, 4, False))
+            self.multi_level_kps.append(ConvDPUnit(chn, self.NK * 2, False))
+            self.multi_level_obj.append(ConvDPUnit(chn, 1, False))
+
+    def init_weights(self):
+        yunet_init_weights(self)
+
+    # ------------------------------------------------------------------ stand-alone forward
+    @torch.no_grad()
+    def forward(self, feats):
+        """NCHW feature maps -> (cls_preds, bbox_preds, obj_preds, kps_preds) lists of NCHW
+        maps (yunet_head.py:175-247), via ONE fused 64->16 HIP unit per level."""
+        feats = list(feats)
+        if self.shared_stack_convs > 0:
+            feats = [convs(f) for f, convs in zip(feats, self.multi_level_share_convs)]
+        outs = ([], [], [], [])
+        for l, f in enumerate(feats):
+            c = f.shape[1]
+            units = (self.multi_level_cls[l], self.multi_level_bbox[l], self.multi_level_obj[l],
+                     self.multi_level_kps[l])
+            w1 = torch.cat([u.conv1.weight.detach().reshape(-1, c) for u in units]).contiguous()
+            b1 = torch.cat([u.conv1.bias.detach() for u in units]).contiguous()
+            w2 = torch.cat([u.conv2.weight.detach().reshape(-1, 9) for u in units]).contiguous()
+            b2 = torch.cat([u.conv2.bias.detach() for u in units]).contiguous()
+            z = K.dp_fwd(f.float().permute(0, 2, 3, 1).contiguous(), w1, b1, w2, b2)
+            z = z.permute(0, 3, 1, 2)
+            for o, (a, b) in zip(outs, ((0, 1), (1, 5), (5, 6), (6, 16))):
+                o.append(z[:, a:b].contiguous())
+        return outs
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_keypointss=None,
+                      gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        outs = self(x)
+        return self.loss(*outs, gt_bboxes, gt_labels, gt_keypointss, img_metas,
+                         gt_bboxes_ignore=gt_bboxes_ignore)
+
+    # ------------------------------------------------------------------ loss
+    def loss_cfg(self):
+        box = type(self.loss_bbox).__name__
+        return K.make_loss_cfg(box, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
+                               self.loss_obj.loss_weight, self.loss_kps.loss_weight,
+                               self.loss_bbox.eps, getattr(self.loss_bbox, 'smooth_point', 0.1),
+                               self.loss_kps.beta)
+
+    def loss(self, cls_scores, bbox_preds, objectnesses, kps_preds, gt_bboxes, gt_labels,
+             gt_kpss, img_metas, gt_bboxes_ignore=None):
+        """Same arguments and returned dict as yunet_head.py:418-534.  Differentiable w.r.t.
+        the prediction maps."""
+        num_imgs = len(img_metas)
+        sizes = [tuple(c.shape[2:]) for c in cls_scores]
+        per_level = []
+        for c, b, o, k in zip(cls_scores, bbox_preds, objectnesses, kps_preds):
+            m = torch.cat([c, b, o, k], dim=1).float()
+            per_level.append(m.permute(0, 2, 3, 1).reshape(num_imgs, -1, m.shape[1]))
+        flat = torch.cat(per_level, dim=1).contiguous()
+        gb, gk, cnt = pad_gt(gt_bboxes, gt_kpss, flat.device)
+        world = torch.distributed.get_world_size() if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        radius = self.assigner.center_radius if self.assigner is not None else 2.5
+        l_cls, l_box, l_obj, l_kps, gi = _LossStep.apply(
+            flat, gb, gk, cnt, sizes, self.strides, self.loss_cfg(), radius, world, None)
+        self.last_gt_inds = gi
+        return dict(loss_cls=l_cls, loss_bbox=l_box, loss_obj=l_obj, loss_kps=l_kps)
+
+    def get_bboxes(self, *args, **kwargs):
+        raise NotImplementedError('inference post-processing (decode + NMS) is the next scope '
+                                  'row (SURVEY.md 8f); this build accelerates the training path')

@@ -10,6 +10,7 @@ import os as _os
 _dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)),
                      'libfacedetection.train_amd')
 __path__ = [_dir]
+__package__ = 'yunet_amd'
 __file__ = _os.path.join(_dir, '__init__.py')
 with open(__file__) as _f:
     exec(compile(_f.read(), __file__, 'exec'))
