@@ -43,6 +43,7 @@ def parse():
     p.add_argument('--size', type=int, default=H)
     p.add_argument('--kind', default=KIND, choices=['n', 's'])
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     p.add_argument('--no-roofline', action='store_true')
     return p.parse_args()
 
@@ -126,36 +127,76 @@ def profile_ops(eng, reps=3):
     return agg
 
 
-def cpu_baseline(kind, size, seed=1234):
-    """The CPU oracle's full training step on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import yunet_oracle as O
-    import yunet_amd.synthetic as S
+def effective_cores():
+    """Host cores actually usable by this process (affinity mask, capped by the cgroup quota)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+        except Exception:
+            pass
+    return cores
+
+
+def cpu_baseline_worker(kind, size, seed=1234, budget_s=12.0):
+    """The CPU oracle's full training step on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import yunet_oracle as O
+    import yunet_amd.synthetic as S
+    cores = effective_cores()
     torch.set_num_threads(cores)
     arch = O.yunet_arch(kind)
     sd = O.init_state(arch, seed=0)
     opt = O.SGD(lr=1e-5)
-    bs = 32
+    bs = 16
     b = S.make_batch(bs, size, size, seed)
     O.train_step(b, sd, arch, opt)          # warm-up
     t0 = time.time()
     iters = 0
-    while iters < 3 or (time.time() - t0 < 10.0 and iters < 20):
+    while iters < 2 or (time.time() - t0 < budget_s and iters < 50):
         O.train_step(b, sd, arch, opt)
         iters += 1
     dt = time.time() - t0
     return dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
-                sample=f'oracle/yunet_oracle.py train_step, YuNet_{kind} {size}x{size} bs {bs}, '
-                       f'{iters} iters after 1 warm-up, torch CPU fp32, {cores} threads')
+                sample=f'oracle/yunet_oracle.py train_step (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} '
+                       f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch CPU fp32, '
+                       f'{cores} threads')
+
+
+def cpu_baseline(kind, size):
+    """Run the worker in a child process with a hard wall-clock bound."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only',
+                              '--kind', kind, '--size', str(size)], capture_output=True,
+                             text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(value=None, unit='images/sec', cores=effective_cores(), kind='port',
+                    sample='cpu baseline worker produced no result: ' + out.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='images/sec', cores=effective_cores(), kind='port',
+                    sample='cpu baseline worker exceeded its 240 s bound')
 
 
 def main():
     a = parse()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_worker(a.kind, a.size)))
+        return
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))

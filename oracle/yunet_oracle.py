@@ -495,6 +495,6 @@ def train_step(batch, sd, arch, opt=None):
             sd[k] = work[k]
     if opt is not None:
         opt.step(sd, grads)
-    log_vars = {k: float(v) for k, v in losses.items()}
-    log_vars['loss'] = float(loss)
+    log_vars = {k: float(v.detach()) for k, v in losses.items()}
+    log_vars["loss"] = float(loss.detach())
     return log_vars, grads, aux

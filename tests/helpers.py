@@ -46,3 +46,17 @@ def image_near_tie(flat_n, gt_boxes_n, sizes, strides=(8, 16, 32), rel=4e-7):
     if two.shape[1] > 1 and float(((two[:, 1] - two[:, 0]) / two[:, 0].abs()).min()) <= rel:
         return True
     return False
+
+
+def fp64_conv_grads(batch, sd, arch, dflat):
+    """d(sum(flat * dflat))/d(params) of the conv stack in fp64: the yardstick against which both
+    fp32 implementations (the oracle port and the HIP path) are measured."""
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    keys = O.param_keys(sd64)
+    leaf = {k: sd64[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sd64)
+    work.update(leaf)
+    maps = O.conv_stack_forward(batch['img'].double(), work, arch, True)
+    flat = O.flatten_preds(*maps)
+    (flat * dflat.double()).sum().backward()
+    return {k: leaf[k].grad for k in keys}
