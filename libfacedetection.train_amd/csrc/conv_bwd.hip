@@ -689,22 +689,24 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ bstats, float* _
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
 }
 
-// out[j] (+)= sum_b partials[b][j]: one thread per column, fixed order, coalesced rows
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials,
-                                                              int blocks, int width,
-                                                              float* __restrict__ out,
-                                                              int accumulate) {
-    // 4 row-slices per block (64 columns x 4 slices), then a fixed-order combine
-    __shared__ float s[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sl = threadIdx.x >> 6;
+// out[j] (+)= sum_b partials[b][j]: 64 columns x 16 row-slices per workgroup (coalesced 256-byte
+// row segments, 16 loads in flight per column), combined in a fixed order -> deterministic.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials,
+                                                               int blocks, int width,
+                                                               float* __restrict__ out,
+                                                               int accumulate) {
+    __shared__ float s[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
     float v = 0.0f;
     if (col < width)
-        for (int b = sl; b < blocks; b += 4) v += partials[(size_t)b * width + col];
-    s[sl][threadIdx.x & 63] = v;
+        for (int b = sl; b < blocks; b += 16) v += partials[(size_t)b * width + col];
+    s[sl][lane] = v;
     __syncthreads();
     if (sl == 0 && col < width) {
-        const float t = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][lane];
         out[col] = accumulate ? out[col] + t : t;
     }
 }
@@ -774,7 +776,7 @@ extern "C" int yunet_bn_param_grad(const double* bstats, float* dgamma, float* d
 extern "C" int yunet_reduce_partials(const float* partials, int blocks, int width, float* out,
                                      int accumulate, void* stream) {
     if (blocks < 1 || width < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64), dim3(256), 0,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64), dim3(1024), 0,
                        (hipStream_t)stream, partials, blocks, width, out, accumulate);
     return hip_status();
 }

@@ -534,6 +534,13 @@ class YuNetEngine:
     def stage_gt(self, plan, gt_bboxes, gt_keypointss):
         """Ragged per-image lists -> padded device buffers with O(1) kernel launches."""
         n = plan.n
+        pb, pk = getattr(gt_bboxes, 'padded', None), getattr(gt_keypointss, 'padded', None)
+        if pb is not None and pk is not None and pb.shape[1] == plan.gmax and pb.is_cuda:
+            # fast path: the data source already padded the GT (synthetic.GTList)
+            plan.gt_boxes.copy_(pb, non_blocking=True)
+            plan.gt_kps.copy_(pk, non_blocking=True)
+            plan.gt_count.copy_(gt_bboxes.counts, non_blocking=True)
+            return
         counts = [int(b.shape[0]) for b in gt_bboxes]
         tot = sum(counts)
         plan.gt_count.copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=True)
@@ -569,7 +576,9 @@ class YuNetEngine:
         losses[4] = (loss_cls, loss_bbox, loss_obj, loss_kps)."""
         assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
         n, _, h, w = img.shape
-        max_gt = max([int(b.shape[0]) for b in gt_bboxes] + [1])
+        pb = getattr(gt_bboxes, 'padded', None)
+        max_gt = int(pb.shape[1]) if pb is not None else \
+            max([int(b.shape[0]) for b in gt_bboxes] + [1])
         plan = self.get_plan(n, h, w, max_gt)
         self.plan = plan
         self._img = img

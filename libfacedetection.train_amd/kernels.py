@@ -47,14 +47,21 @@ def conv_blocks():
     return L.load().yunet_conv_blocks()
 
 
+# Persistent grids of the backward kernels (= rows of their weight-gradient partials).
+# dp_bwd uses 512 threads and up to 138 KB of LDS: one workgroup per CU is resident, so 256
+# workgroups cover the chip; stem_bwd (256 threads, 34 KB) fits three per CU.
+DP_BWD_BLOCKS = 256
+STEM_BWD_BLOCKS = 768
+
+
 def dp_grid(n, h, w):
     tiles = n * ((w + 15) // 16) * ((h + 7) // 8)
-    return min(tiles, conv_blocks())
+    return min(tiles, DP_BWD_BLOCKS)
 
 
 def stem_grid(n, h, w):
     tiles = n * ((w // 2 + 31) // 32) * ((h // 2 + 7) // 8)
-    return min(tiles, conv_blocks())
+    return min(tiles, STEM_BWD_BLOCKS)
 
 
 def dp_row_width(cin, cout):

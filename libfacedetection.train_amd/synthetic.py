@@ -22,6 +22,40 @@ WIDER_VAL_FACES_HIST = [
 MAX_GT = 64
 
 
+class GTList(list):
+    """A per-image list of GT tensors (what the reference's collate delivers,
+    mmdet/datasets/pipelines/formatting.py:232-238) that also carries the same data padded to
+    [N, Gmax, ...] plus the per-image counts, prepared by the data source on the CPU so the
+    training step does not loop over images on the host."""
+    padded = None      # [N, Gmax, ...] tensor
+    counts = None      # [N] int32 tensor
+
+
+def _pad(lst, tail, gmax):
+    n = len(lst)
+    out = torch.zeros((n, gmax) + tail, dtype=torch.float32)
+    cnt = torch.zeros(n, dtype=torch.int32)
+    for i, t in enumerate(lst):
+        g = int(t.shape[0])
+        out[i, :g] = t
+        cnt[i] = g
+    return out, cnt
+
+
+def attach_padding(batch, max_gt=None):
+    """Turn the ragged GT lists of a batch dict into GTLists with padded companions."""
+    gmax = 64
+    need = max([int(b.shape[0]) for b in batch['gt_bboxes']] + [1])
+    while gmax < need:
+        gmax *= 2
+    gb = GTList(batch['gt_bboxes'])
+    gb.padded, gb.counts = _pad(batch['gt_bboxes'], (4,), gmax)
+    gk = GTList(batch['gt_keypointss'])
+    gk.padded, gk.counts = _pad(batch['gt_keypointss'], (5, 3), gmax)
+    batch['gt_bboxes'], batch['gt_keypointss'] = gb, gk
+    return batch
+
+
 def batch_seed(rank, it):
     return 1234 + 1000 * rank + it
 
@@ -64,8 +98,8 @@ def make_batch(num_imgs, height, width, seed, max_gt=MAX_GT, with_img=True):
     metas = [dict(img_shape=(height, width, 3), pad_shape=(height, width, 3),
                   scale_factor=1.0, flip=False, filename=f'synthetic_{seed}_{i}')
              for i in range(num_imgs)]
-    return dict(img=img, img_metas=metas, gt_bboxes=gt_bboxes, gt_labels=gt_labels,
-                gt_keypointss=gt_kps)
+    return attach_padding(dict(img=img, img_metas=metas, gt_bboxes=gt_bboxes,
+                               gt_labels=gt_labels, gt_keypointss=gt_kps))
 
 
 def to_device(batch, device):
@@ -73,5 +107,11 @@ def to_device(batch, device):
     if batch['img'] is not None:
         out['img'] = batch['img'].to(device, non_blocking=True)
     for k in ('gt_bboxes', 'gt_labels', 'gt_keypointss'):
-        out[k] = [t.to(device, non_blocking=True) for t in batch[k]]
+        moved = [t.to(device, non_blocking=True) for t in batch[k]]
+        src = batch[k]
+        if isinstance(src, GTList) and src.padded is not None:
+            moved = GTList(moved)
+            moved.padded = src.padded.to(device, non_blocking=True)
+            moved.counts = src.counts.to(device, non_blocking=True)
+        out[k] = moved
     return out

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark at the headline shapes (YuNet_n 320x320 bs 256): times single
+launches with events on the launch stream and prints achieved algorithmic GB/s.
+
+    python tools/kbench.py [--reps 10] [--only dp_fwd64]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import yunet_amd.kernels as K  # noqa: E402
+
+DEV = 'cuda'
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def unit(ci, co):
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    return (torch.randn(co, ci, generator=g).to(DEV) * 0.1, torch.randn(co, generator=g).to(DEV) * .1,
+            torch.randn(co, 9, generator=g).to(DEV) * 0.3, torch.randn(co, generator=g).to(DEV) * .1)
+
+
+def stats_like(x):
+    c = x.shape[-1]
+    v = x.reshape(-1, c)[:65536].double()
+    n = x.numel() // c
+    return torch.cat([v.mean(0) * n, (v * v).mean(0) * n]).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--n', type=int, default=256)
+    a = ap.parse_args()
+    N = a.n
+    cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
+             ('dp64_40', 64, 64, 40, 40), ('head', 64, 16, 40, 40)]
+    for name, ci, co, h, w in cases:
+        if a.only and a.only not in name:
+            continue
+        x = torch.randn(N, h, w, ci, device=DEV)
+        wp, bp, wd, bd = unit(ci, co)
+        gam, bet = torch.ones(ci, device=DEV), torch.zeros(ci, device=DEV)
+        in_bn = K.BN(stats_like(x), gam, bet, N * h * w, bstats=torch.zeros(2 * ci, dtype=torch.float64, device=DEV))
+        ostats = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+        has_bn = co != 16 or ci != 64
+        out_bn = K.BN(ostats, torch.ones(co, device=DEV), torch.zeros(co, device=DEV), N * h * w,
+                      bstats=torch.zeros(2 * co, dtype=torch.float64, device=DEV)) if has_bn else None
+        z = torch.empty(N, h, w, co, device=DEV)
+        t = timeit(lambda: K.dp_fwd(x, wp, bp, wd, bd, in_bn, out_bn, z=z), a.reps)
+        px = N * h * w
+        by = px * (ci + co) * 4
+        print(f'{name:8s} fwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s  {t * 1e-3 * 2.4e9 * 256 / px:7.1f} CUcyc/px')
+        dy = torch.randn(N, h, w, co, device=DEV)
+        dx = torch.empty_like(x)
+        if out_bn is not None:
+            out_bn.stats = stats_like(z)
+        blocks = K.dp_grid(N, h, w)
+        part = torch.empty(blocks, K.dp_row_width(ci, co), device=DEV)
+        import ctypes as C
+        import yunet_amd._lib as L
+        d = K._dp_desc(x, wp, bp, wd, bd, z, in_bn, out_bn)
+        d.dy, d.dx = dy.data_ptr(), dx.data_ptr()
+        d.wgrad_partials, d.wgrad_blocks = part.data_ptr(), blocks
+        lib = L.load()
+        t = timeit(lambda: L.check(lib.yunet_dp_bwd(C.byref(d), K._stream()), 'bwd'), a.reps)
+        by = px * (2 * ci + co) * 4
+        print(f'{name:8s} bwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s  {t * 1e-3 * 2.4e9 * 256 / px:7.1f} CUcyc/px')
+        out = torch.empty(part.shape[1], device=DEV)
+        t = timeit(lambda: K.reduce_partials(part, out), a.reps)
+        print(f'{name:8s} red  {t:8.4f} ms  rows={blocks}')
+    if not a.only or 'stem' in a.only:
+        img = torch.rand(N, 3, 320, 320, device=DEV) * 255
+        w = torch.randn(16, 3, 3, 3, device=DEV) * 0.05
+        b = torch.zeros(16, device=DEV)
+        st = torch.zeros(32, dtype=torch.float64, device=DEV)
+        t = timeit(lambda: K.stem_fwd(img, w, b, st), a.reps)
+        by = N * (3 * 320 * 320 + 16 * 160 * 160) * 4
+        print(f'stem     fwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s')
+
+
+if __name__ == '__main__':
+    main()
