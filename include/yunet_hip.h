@@ -71,6 +71,7 @@ typedef struct YunetDP {
                                   (ReLU mask applied) or wrt x if IDENTITY; NULL skips */
     float* wgrad_partials;     /* [nblocks, cout*cin + cout + cout*9 + cout] fp32     */
     int32_t wgrad_blocks;      /* number of partial rows (= launch grid)              */
+    unsigned long long* prof;  /* optional [grid,8] per-workgroup phase cycle counters (or NULL) */
 } YunetDP;
 
 /* ---- conv stack (mmdet/models/utils/yunet_layer.py, backbones/yunet_backbone.py:33-41,

@@ -32,7 +32,8 @@ class YunetDP(C.Structure):
                 ('w_pw', C.c_void_p), ('b_pw', C.c_void_p), ('w_dw', C.c_void_p),
                 ('b_dw', C.c_void_p), ('z', C.c_void_p), ('out_bn', YunetBN),
                 ('dy', C.c_void_p), ('dy_scale', C.c_void_p), ('dx', C.c_void_p),
-                ('wgrad_partials', C.c_void_p), ('wgrad_blocks', C.c_int32)]
+                ('wgrad_partials', C.c_void_p), ('wgrad_blocks', C.c_int32),
+                ('prof', C.c_void_p)]
 
 
 class YunetLevels(C.Structure):

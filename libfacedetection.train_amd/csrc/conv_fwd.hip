@@ -114,20 +114,30 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 }
 
 // --------------------------------------------------------------------------- ConvDPUnit
+// Per (TH x TW) output tile, 256 threads:
+//   stage : the haloed raw input tile, PREFETCHED into registers during the previous tile's
+//           compute phases, gets the input transform (BN+ReLU of the producer) and goes to LDS
+//   pw    : [pixels x CIN] * [CIN x COUT] on the matrix cores (v_mfma_f32_16x16x4_f32, exact
+//           fp32), result written back in place (a wave owns its 16-pixel M tiles)
+//   dw    : depthwise 3x3 from LDS on the VALU, bias, coalesced store of the raw output,
+//           BN statistics (fp32 per tile, fp64 across tiles)
 template <int CIN, int COUT, int TH, int TW>
 struct DpGeom {
     static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_;
     static constexpr int MT = (HP + 15) / 16, MP = MT * 16;
     static constexpr int CM = CIN > COUT ? CIN : COUT;
     static constexpr int LS = CM + 4;           // LDS row stride (floats), 16-byte aligned rows
+    static constexpr int WS = CIN + 2;          // pointwise-weight row stride in LDS
     static constexpr int C4I = CIN / 4, C4O = COUT / 4;
     static constexpr int NT = COUT / 16, KS = CIN / 4;
     static constexpr int PG = 256 / C4O;        // pixel groups in the depthwise phase
     static constexpr int RG = PG / TW;          // row groups
     static constexpr int RPT = TH / RG;         // output rows per thread
+    static constexpr int NLD = (HP * C4I + 255) / 256;   // float4 loads per thread per tile
     static constexpr size_t BUF_BYTES = (size_t)MP * LS * 4;
     static constexpr size_t RED_BYTES = 256 * 8 * 8;
-    static constexpr size_t SMEM = (BUF_BYTES > RED_BYTES ? BUF_BYTES : RED_BYTES) + 3 * CIN * 4;
+    static constexpr size_t BUFB = BUF_BYTES > RED_BYTES ? BUF_BYTES : RED_BYTES;
+    static constexpr size_t SMEM = BUFB + (size_t)(COUT * WS + 9 * COUT + COUT + 3 * CIN) * 4;
     static_assert(PG % TW == 0 && TH % RG == 0, "tile / thread mapping");
     static_assert(256 % C4I == 0, "load mapping");
 };
@@ -137,95 +147,105 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     using G = DpGeom<CIN, COUT, TH, TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* buf = reinterpret_cast<float*>(smem_raw);
-    constexpr size_t BUFB = G::BUF_BYTES > G::RED_BYTES ? G::BUF_BYTES : G::RED_BYTES;
-    float* s_coef = reinterpret_cast<float*>(smem_raw + BUFB);  // mean | scale | beta
+    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::BUFB);   // [COUT][WS]
+    float* s_w2 = s_w1 + COUT * G::WS;                            // [9][COUT]
+    float* s_b2 = s_w2 + 9 * COUT;                                // [COUT]
+    float* s_coef = s_b2 + COUT;                                  // mean | scale | beta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int H = d.H, W = d.W;
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
 
-    if (bn_in) {
-        for (int c = tid; c < CIN; c += 256) {
-            const BNCoef k = bn_coef(d.in_bn, CIN, c);
-            s_coef[c] = k.mean;
-            s_coef[CIN + c] = k.scale;
-            s_coef[2 * CIN + c] = k.beta;
-        }
+    for (int i = tid; i < COUT * CIN; i += 256) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+    for (int i = tid; i < COUT * 9; i += 256) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
+    for (int i = tid; i < COUT; i += 256) s_b2[i] = d.b_dw[i];
+    for (int c = tid; c < CIN; c += 256) {
+        BNCoef k{0.f, 1.f, 0.f, 1.f};
+        if (bn_in) k = bn_coef(d.in_bn, CIN, c);
+        s_coef[c] = k.mean;
+        s_coef[CIN + c] = k.scale;
+        s_coef[2 * CIN + c] = k.beta;
     }
-    // pointwise weights as MFMA B fragments, resident in registers for the whole kernel:
-    // B[k = ci][n = co] = w_pw[co][ci]
-    float Bf[G::KS][G::NT];
     float bias_pw[G::NT];
 #pragma unroll
-    for (int nt = 0; nt < G::NT; ++nt) {
-        bias_pw[nt] = d.b_pw[nt * 16 + l15];
-#pragma unroll
-        for (int s = 0; s < G::KS; ++s) Bf[s][nt] = d.w_pw[(nt * 16 + l15) * CIN + 4 * s + g];
-    }
-    // depthwise: this thread owns channels cq*4..cq*4+3
+    for (int nt = 0; nt < G::NT; ++nt) bias_pw[nt] = d.b_pw[nt * 16 + l15];
+    // depthwise: this thread owns channels cq*4..cq*4+3, column dtx, rows r0..r0+RPT-1
     const int cq = tid % G::C4O, pg = tid / G::C4O;
     const int dtx = pg % TW, r0 = (pg / TW) * G::RPT;
-    float4 w2[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-        w2[t] = make_float4(d.w_dw[(cq * 4 + 0) * 9 + t], d.w_dw[(cq * 4 + 1) * 9 + t],
-                            d.w_dw[(cq * 4 + 2) * 9 + t], d.w_dw[(cq * 4 + 3) * 9 + t]);
-    const float4 b2 = *reinterpret_cast<const float4*>(d.b_dw + cq * 4);
     double st[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = 0.0;
-    __syncthreads();
     const int lch4 = tid % G::C4I;  // input channel quad of this thread in the load phase
-    float4 cm = make_float4(0, 0, 0, 0), cs = cm, cb = cm;
-    if (bn_in) {
-        cm = *reinterpret_cast<const float4*>(s_coef + lch4 * 4);
-        cs = *reinterpret_cast<const float4*>(s_coef + CIN + lch4 * 4);
-        cb = *reinterpret_cast<const float4*>(s_coef + 2 * CIN + lch4 * 4);
-    }
+    __syncthreads();
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int ntiles = d.N * tiles_x * tiles_y;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int n = t / (tiles_x * tiles_y);
-        const int rr = t - n * tiles_x * tiles_y;
+    const int tiles_img = tiles_x * tiles_y;
+    const int ntiles = d.N * tiles_img;
+
+    // prefetch registers: this thread's slice of the NEXT tile's raw halo input
+    float4 pre[G::NLD];
+    auto issue = [&](int t) {
+        const int n = t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const float* xin = d.x + (size_t)n * d.x_img_stride;
-        // ---- phase 1: haloed input tile -> LDS (input transform applied) ----------------------
-        for (int q = tid; q < G::HP * G::C4I; q += 256) {
-            const int hp = q / G::C4I;
+        const float* xin = d.x + (size_t)n * d.x_img_stride + lch4 * 4;
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) {
+            const int hp = (tid + 256 * i) / G::C4I;
             const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                v = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN + lch4 * 4);
-                if (bn_in) {
-                    v.x = bnrelu(v.x, cm.x, cs.x, cb.x);
-                    v.y = bnrelu(v.y, cm.y, cs.y, cb.y);
-                    v.z = bnrelu(v.z, cm.z, cs.z, cb.z);
-                    v.w = bnrelu(v.w, cm.w, cs.w, cb.w);
-                }
-            }
-            *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
+            pre[i] = make_float4(0, 0, 0, 0);
+            if (hp < G::HP && y >= 0 && y < H && x >= 0 && x < W)
+                pre[i] = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN);
         }
-        if (G::MP > G::HP) {  // padding rows of the last M tile: keep them finite
-            for (int q = tid; q < (G::MP - G::HP) * G::C4I; q += 256) {
-                const int hp = G::HP + q / G::C4I;
-                *reinterpret_cast<float4*>(buf + hp * G::LS + (q % G::C4I) * 4) = make_float4(0, 0, 0, 0);
+    };
+
+    unsigned long long pc[4] = {0, 0, 0, 0}, c0 = 0;
+    const bool prof = d.prof != nullptr;
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        if (prof) c0 = clock64();
+        const int n = t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        // ---- stage: registers -> LDS with the input transform ----------------------------------
+        {
+            const float4 cm = *reinterpret_cast<const float4*>(s_coef + lch4 * 4);
+            const float4 cs = *reinterpret_cast<const float4*>(s_coef + CIN + lch4 * 4);
+            const float4 cb = *reinterpret_cast<const float4*>(s_coef + 2 * CIN + lch4 * 4);
+#pragma unroll
+            for (int i = 0; i < G::NLD; ++i) {
+                const int hp = (tid + 256 * i) / G::C4I;
+                if (hp < G::MP) {
+                    const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                    float4 v = pre[i];
+                    if (bn_in && hp < G::HP && y >= 0 && y < H && x >= 0 && x < W) {
+                        v.x = bnrelu(v.x, cm.x, cs.x, cb.x);
+                        v.y = bnrelu(v.y, cm.y, cs.y, cb.y);
+                        v.z = bnrelu(v.z, cm.z, cs.z, cb.z);
+                        v.w = bnrelu(v.w, cm.w, cs.w, cb.w);
+                    }
+                    *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
+                }
             }
         }
         __syncthreads();
-        // ---- phase 2: pointwise 1x1 as [pixels x CIN] * [CIN x COUT] on the matrix cores,
-        //      result written back IN PLACE (a wave owns its 16-pixel M tiles) -------------------
+        if (prof) { const unsigned long long c = clock64(); pc[0] += c - c0; c0 = c; }
+        // the registers are free again: fetch the next tile while this one is computed
+        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x);
+        // ---- pw: pointwise 1x1 on the matrix cores, in place ------------------------------------
         for (int mt = wid; mt < G::MT; mt += 4) {
             f32x4 acc[G::NT];
 #pragma unroll
             for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* arow = buf + (mt * 16 + l15) * G::LS + g;
+            const float* brow = s_w1 + l15 * G::WS + g;     // B[k = ci][n = co] = w_pw[co][ci]
 #pragma unroll
             for (int s = 0; s < G::KS; ++s) {
                 const float a = arow[4 * s];
 #pragma unroll
-                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a, Bf[s][nt], acc[nt]);
+                for (int nt = 0; nt < G::NT; ++nt)
+                    acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -241,10 +261,18 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
             }
         }
         __syncthreads();
-        // ---- phase 3: depthwise 3x3 from LDS, bias, store raw z, BN statistics -----------------
+        if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }
+        // ---- dw: depthwise 3x3 from LDS, bias, store raw z, BN statistics ------------------------
         {
             float* zout = d.z + (size_t)n * d.z_img_stride;
             const float* pbase = buf + dtx * G::LS + cq * 4;
+            float4 w2[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w2[k] = *reinterpret_cast<const float4*>(s_w2 + k * COUT + cq * 4);
+            const float4 b2 = *reinterpret_cast<const float4*>(s_b2 + cq * 4);
+            float ts[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ts[i] = 0.0f;
             float4 rowA[3], rowB[3], rowC[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -269,9 +297,9 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                 const int y = y0 + r0 + r, x = x0 + dtx;
                 if (y < H && x < W) {
                     *reinterpret_cast<float4*>(zout + ((size_t)y * W + x) * COUT + cq * 4) = o;
-                    st[0] += (double)o.x; st[1] += (double)o.y; st[2] += (double)o.z; st[3] += (double)o.w;
-                    st[4] += (double)o.x * o.x; st[5] += (double)o.y * o.y;
-                    st[6] += (double)o.z * o.z; st[7] += (double)o.w * o.w;
+                    ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
+                    ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
+                    ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -279,8 +307,15 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                     rowB[j] = rowC[j];
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st[i] += (double)ts[i];
         }
+        if (prof) { const unsigned long long c = clock64(); pc[2] += c - c0; c0 = c; }
         __syncthreads();
+        if (prof) { const unsigned long long c = clock64(); pc[3] += c - c0; c0 = c; }
+    }
+    if (prof && (tid & 63) == 0) {
+        for (int i = 0; i < 4; ++i) d.prof[(blockIdx.x * 4 + wid) * 4 + i] = pc[i];
     }
     // ---- BN statistics of this unit's output: block reduce in LDS, one fp64 atomic per channel
     if (d.out_has_bn) {
@@ -301,14 +336,19 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
 template <int CIN, int COUT, int TH, int TW>
 int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
     using G = DpGeom<CIN, COUT, TH, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        attr_set = true;
+    static int blocks_per_cu = 0;
+    if (!blocks_per_cu) {
+        const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW>);
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
+            nb = 1;
+        blocks_per_cu = nb > 4 ? 4 : nb;
     }
+    // persistent grid: exactly the resident workgroups, so every one pipelines many tiles
     const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
-    const int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    const int resident = 256 * blocks_per_cu;
+    const int grid = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW>), dim3(grid), dim3(256), G::SMEM, stream, *d);
     return hip_status();
 }
@@ -413,6 +453,8 @@ extern "C" int yunet_dp_fwd(const YunetDP* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
+    if (d->cin == 16 && d->cout == 16 && d->W >= 64 && d->H >= 32)
+        return launch_dp_fwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
     ap.add_argument('--n', type=int, default=256)
+    ap.add_argument('--prof', action='store_true')
     a = ap.parse_args()
     N = a.n
     cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
@@ -63,6 +64,17 @@ def main():
                       bstats=torch.zeros(2 * co, dtype=torch.float64, device=DEV)) if has_bn else None
         z = torch.empty(N, h, w, co, device=DEV)
         t = timeit(lambda: K.dp_fwd(x, wp, bp, wd, bd, in_bn, out_bn, z=z), a.reps)
+        if a.prof:
+            import ctypes as C
+            import yunet_amd._lib as L
+            dd = K._dp_desc(x, wp, bp, wd, bd, z, in_bn, out_bn)
+            pr = torch.zeros(4096, 16, dtype=torch.int64, device=DEV)
+            dd.prof = pr.data_ptr()
+            L.check(L.load().yunet_dp_fwd(C.byref(dd), K._stream()), 'fwd')
+            torch.cuda.synchronize()
+            v = pr.view(-1, 4).double()
+            v = v[v.sum(1) > 0]
+            print('   fwd phase cycles/wave (stage, pw, dw, endbar):', [int(x) for x in v.mean(0).tolist()], 'waves', v.shape[0], 'max total', int(v.sum(1).max()))
         px = N * h * w
         by = px * (ci + co) * 4
         print(f'{name:8s} fwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s  {t * 1e-3 * 2.4e9 * 256 / px:7.1f} CUcyc/px')
