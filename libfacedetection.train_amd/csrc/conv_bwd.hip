@@ -31,24 +31,26 @@ struct BwdGeom {
     static constexpr int TPW = NTILE >= BWD_WAVES ? NTILE / BWD_WAVES : 1;
     static constexpr int KSPLIT = NTILE >= BWD_WAVES ? 1 : BWD_WAVES / NTILE;
     static constexpr int KSTEPS = (IP / 4) / KSPLIT;  // k-steps of 4 pixels per wave
+    static constexpr int NDZ = (HP * C4O + BWD_THREADS - 1) / BWD_THREADS;  // (dy,z) float4 pairs / thread
+    static constexpr int NX = (IP * C4I) / BWD_THREADS;                       // x float4 / thread
     // LDS carve (floats)
     static constexpr int OFF_DZ = 0;
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
-    static constexpr int OFF_W1 = OFF_PB + IP * LSO;
-    static constexpr int OFF_CO = OFF_W1 + COUT * WS;   // out-bn bwd coefs 5*COUT
-    static constexpr int OFF_CI = OFF_CO + 5 * COUT;    // in-bn coefs 4*CIN
-    static constexpr int TOTAL = OFF_CI + 4 * CIN;
+    static constexpr int WORK_F = OFF_PB + IP * LSO;
+    static constexpr int PAR_F = COUT * WS + 9 * COUT + 5 * COUT + 4 * CIN;   // w1 | w2 | out-bn | in-bn
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
     static constexpr size_t RED2 = (size_t)BWD_THREADS * 8 * 8;       // bstats reduction
-    static constexpr size_t WORK = (size_t)OFF_W1 * 4;
+    static constexpr size_t WORK = (size_t)WORK_F * 4;
     static constexpr size_t WORKB = WORK > RED1 ? (WORK > RED2 ? WORK : RED2) : (RED1 > RED2 ? RED1 : RED2);
-    static constexpr size_t SMEM = WORKB + (size_t)(TOTAL - OFF_W1) * 4;
+    static constexpr size_t SMEM = WORKB + (size_t)PAR_F * 4;
     static_assert(IP % 16 == 0 && IMT == BWD_WAVES, "one 16-pixel M tile per wave");
     static_assert(PG % TW == 0 && IP % PG == 0, "VALU mapping");
     static_assert(BWD_THREADS % C4I == 0 && BWD_THREADS % C4O == 0, "load mapping");
+    static_assert((IP * C4I) % BWD_THREADS == 0, "x load mapping");
     static_assert((IP / 4) % KSPLIT == 0, "k split");
+    static_assert(TPW == 1 || NTO % TPW == 0, "a wave's dW1 tiles share the ci block");
 };
 
 template <int CIN, int COUT, int TH, int TW>
@@ -60,20 +62,21 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     float* s_a = sm + G::OFF_A;
     float* s_pb = sm + G::OFF_PB;
     // the parameter/coefficient block sits after the (possibly larger) reduction work area
-    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);
-    float* s_co = s_w1 + COUT * G::WS;
-    float* s_ci = s_co + 5 * COUT;
+    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);   // [COUT][WS]
+    float* s_w2 = s_w1 + COUT * G::WS;                             // [9][COUT]
+    float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2
+    float* s_ci = s_co + 5 * COUT;                                 // mean|scale|beta|invstd
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int H = d.H, W = d.W;
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
     const bool bn_out = d.out_has_bn != 0;
+    // debug ablation mask (tools/kbench.py --ablate): prof < 4096 is a bit mask, not a pointer
+    const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
 
-    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
-        const int co = i / CIN, ci = i - co * CIN;
-        s_w1[co * G::WS + ci] = d.w_pw[i];
-    }
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+    for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
     for (int c = tid; c < COUT; c += BWD_THREADS) {
         if (bn_out) {
             const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
@@ -97,107 +100,127 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     __syncthreads();
 
     // ---- per-thread constants ---------------------------------------------------------------
-    const int och4 = tid % G::C4O;   // output-channel quad in the dz load phase
-    const int ich4 = tid % G::C4I;   // input-channel quad in the a load / final phases
-    // (the per-channel BN constants stay in LDS and are re-read per phase: keeping them
-    //  live across the MFMA phases costs ~36 VGPRs and pushes the kernel into spills)
+    const int och4 = tid % G::C4O;   // output-channel quad in the dz stage
+    const int ich4 = tid % G::C4I;   // input-channel quad in the a stage / dx store
     float bias_pw[G::NTO];
 #pragma unroll
     for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = d.b_pw[nt * 16 + l15];
     // VALU phase: channel quad cq, pixel column vtx, rows vr0..vr0+PPT-1
     const int cq = tid % G::C4O, pg = tid / G::C4O;
     const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
-    float4 w2[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-        w2[t] = make_float4(d.w_dw[(cq * 4 + 0) * 9 + t], d.w_dw[(cq * 4 + 1) * 9 + t],
-                            d.w_dw[(cq * 4 + 2) * 9 + t], d.w_dw[(cq * 4 + 3) * 9 + t]);
+    // persistent accumulators (flushed once per workgroup)
     float4 gw2[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) gw2[t] = make_float4(0, 0, 0, 0);
     float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
-    double bst[8];
+    // per-lane fp32 partials of the producer's BN-backward sums, D layout: channel nt*16 + l15
+    float bst[2 * G::NTI];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bst[i] = 0.0;
-    // dW1 accumulators: this wave's 16x16 tiles (m = ci block, n = co block)
-    f32x4 gw1[G::TPW];
+    for (int i = 0; i < 2 * G::NTI; ++i) bst[i] = 0.0f;
+    f32x4 gw1[G::TPW];   // dW1: this wave's 16x16 tiles (m = ci block, n = co block)
 #pragma unroll
     for (int i = 0; i < G::TPW; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int w1_tile0 = G::KSPLIT == 1 ? wid * G::TPW : wid % G::NTILE;
     const int w1_kslice = G::KSPLIT == 1 ? 0 : wid / G::NTILE;
+    const int w1_mt = w1_tile0 / G::NTO, w1_nt0 = w1_tile0 % G::NTO;
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int ntiles = d.N * tiles_x * tiles_y;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int n = t / (tiles_x * tiles_y);
-        const int rr = t - n * tiles_x * tiles_y;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const float* xin = d.x + (size_t)n * d.x_img_stride;
-        const float* zo = d.z + (size_t)n * d.z_img_stride;
-        const float* dyo = d.dy + (size_t)n * d.z_img_stride;
+    const int tiles_img = tiles_x * tiles_y;
+    const int ntiles = d.N * tiles_img;
 
-        // ---- phase 1: dz halo tile and transformed input tile -> LDS ---------------------------
-        {
-        const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
-        const float4 o_inv = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
-        const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
-        const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
-        const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
-        for (int q = tid; q < G::HP * G::C4O; q += BWD_THREADS) {
-            const int hp = q / G::C4O;
+    // ---- prefetch registers: raw dy / z_out (haloed) and x (interior) of the NEXT tile ------------
+    float4 pdy[G::NDZ], pz[G::NDZ], px[G::NX];
+    auto issue = [&](int t) {
+        const int n = t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const float* zo = d.z + (size_t)n * d.z_img_stride + och4 * 4;
+        const float* dyo = d.dy + (size_t)n * d.z_img_stride + och4 * 4;
+        const float* xin = d.x + (size_t)n * d.x_img_stride + ich4 * 4;
+#pragma unroll
+        for (int i = 0; i < G::NDZ; ++i) {
+            const int hp = (tid + BWD_THREADS * i) / G::C4O;
             const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                const size_t off = ((size_t)y * W + x) * COUT + och4 * 4;
-                const float4 dy = *reinterpret_cast<const float4*>(dyo + off);
-                if (bn_out) {
-                    const float4 z = *reinterpret_cast<const float4*>(zo + off);
-                    v.x = o_k1.x * (dy.x - o_c1.x - (z.x - o_mean.x) * o_inv.x * o_c2.x);
-                    v.y = o_k1.y * (dy.y - o_c1.y - (z.y - o_mean.y) * o_inv.y * o_c2.y);
-                    v.z = o_k1.z * (dy.z - o_c1.z - (z.z - o_mean.z) * o_inv.z * o_c2.z);
-                    v.w = o_k1.w * (dy.w - o_c1.w - (z.w - o_mean.w) * o_inv.w * o_c2.w);
-                } else {
-                    v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
-                }
+            pdy[i] = make_float4(0, 0, 0, 0);
+            pz[i] = make_float4(0, 0, 0, 0);
+            if (hp < G::HP && y >= 0 && y < H && x >= 0 && x < W) {
+                const size_t off = ((size_t)y * W + x) * COUT;
+                pdy[i] = *reinterpret_cast<const float4*>(dyo + off);
+                if (bn_out) pz[i] = *reinterpret_cast<const float4*>(zo + off);
             }
-            *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
         }
-        }
-        {
-        const float4 i_mean = *reinterpret_cast<float4*>(s_ci + ich4 * 4);
-        const float4 i_scale = *reinterpret_cast<float4*>(s_ci + CIN + ich4 * 4);
-        const float4 i_beta = *reinterpret_cast<float4*>(s_ci + 2 * CIN + ich4 * 4);
-        for (int q = tid; q < G::IP * G::C4I; q += BWD_THREADS) {
-            const int ip = q / G::C4I;
+#pragma unroll
+        for (int i = 0; i < G::NX; ++i) {
+            const int ip = (tid + BWD_THREADS * i) / G::C4I;
             const int y = y0 + ip / TW, x = x0 + ip % TW;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (y < H && x < W) {
-                v = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN + ich4 * 4);
-                if (bn_in) {
-                    v.x = bnrelu(v.x, i_mean.x, i_scale.x, i_beta.x);
-                    v.y = bnrelu(v.y, i_mean.y, i_scale.y, i_beta.y);
-                    v.z = bnrelu(v.z, i_mean.z, i_scale.z, i_beta.z);
-                    v.w = bnrelu(v.w, i_mean.w, i_scale.w, i_beta.w);
+            px[i] = make_float4(0, 0, 0, 0);
+            if (y < H && x < W)
+                px[i] = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const int n = t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+
+        // ---- stage: dz (BN backward of this unit's own BN) and a = T(x) -> LDS ------------------
+        {
+            const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
+            const float4 o_inv = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
+            const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
+            const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
+            const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
+#pragma unroll
+            for (int i = 0; i < G::NDZ; ++i) {
+                const int hp = (tid + BWD_THREADS * i) / G::C4O;
+                if (hp < G::HP) {
+                    const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                    float4 v = make_float4(0, 0, 0, 0);
+                    if (y >= 0 && y < H && x >= 0 && x < W) {
+                        const float4 dy = pdy[i], z = pz[i];
+                        if (bn_out) {
+                            v.x = o_k1.x * (dy.x - o_c1.x - (z.x - o_mean.x) * o_inv.x * o_c2.x);
+                            v.y = o_k1.y * (dy.y - o_c1.y - (z.y - o_mean.y) * o_inv.y * o_c2.y);
+                            v.z = o_k1.z * (dy.z - o_c1.z - (z.z - o_mean.z) * o_inv.z * o_c2.z);
+                            v.w = o_k1.w * (dy.w - o_c1.w - (z.w - o_mean.w) * o_inv.w * o_c2.w);
+                        } else {
+                            v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
                 }
             }
-            *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = v;
         }
+        // the interior input tile goes to LDS RAW; the input transform (BN+ReLU of the producer)
+        // is applied where MFMA operands are read, so the raw values stay available for the
+        // ReLU mask and the BN-backward sums of the producer
+#pragma unroll
+        for (int i = 0; i < G::NX; ++i) {
+            const int ip = (tid + BWD_THREADS * i) / G::C4I;
+            *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = px[i];
         }
         __syncthreads();
+        // prefetch the next tile's global data while this tile is computed
+        if (t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
 
-        // ---- phase 2: p = a * W1^T + b1 on the interior pixels (one M tile per wave) -----------
-        {
+        // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
+        if (!(abl & 1)) {
             f32x4 acc[G::NTO];
 #pragma unroll
             for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* arow = s_a + (wid * 16 + l15) * G::LSI + g;
+            const float* brow = s_w1 + l15 * G::WS + g;
 #pragma unroll
             for (int s = 0; s < G::KSI; ++s) {
-                const float a = arow[4 * s];
+                const int c = 4 * s + g;
+                const float ar = arow[4 * s];
+                const float a = bn_in ? bnrelu(ar, s_ci[c], s_ci[CIN + c], s_ci[2 * CIN + c]) : ar;
 #pragma unroll
                 for (int nt = 0; nt < G::NTO; ++nt)
-                    acc[nt] = mfma16(a, s_w1[(nt * 16 + l15) * G::WS + 4 * s + g], acc[nt]);
+                    acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -210,9 +233,9 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         }
         __syncthreads();
 
-        // ---- phase 3: depthwise backward on the VALU; dp overwrites p in place ------------------
-#pragma unroll
-        for (int r = 0; r < G::PPT; ++r) {
+        // ---- depthwise backward on the VALU; dp overwrites p in place ----------------------------
+#pragma unroll 1
+        for (int r = 0; r < ((abl & 2) ? 0 : G::PPT); ++r) {
             const int ty = vr0 + r;
             const bool in = (y0 + ty) < H && (x0 + vtx) < W;
             float* pp = s_pb + (ty * TW + vtx) * G::LSO + cq * 4;
@@ -225,8 +248,9 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                     const float4 z4 = *reinterpret_cast<const float4*>(
                         s_dz + ((ty + a) * G::HW_ + vtx + b) * G::LSO + cq * 4);
                     const int k = 8 - (3 * a + b);
-                    dp.x = fmaf(z4.x, w2[k].x, dp.x); dp.y = fmaf(z4.y, w2[k].y, dp.y);
-                    dp.z = fmaf(z4.z, w2[k].z, dp.z); dp.w = fmaf(z4.w, w2[k].w, dp.w);
+                    const float4 wk = *reinterpret_cast<const float4*>(s_w2 + k * COUT + cq * 4);
+                    dp.x = fmaf(z4.x, wk.x, dp.x); dp.y = fmaf(z4.y, wk.y, dp.y);
+                    dp.z = fmaf(z4.z, wk.z, dp.z); dp.w = fmaf(z4.w, wk.w, dp.w);
                     gw2[k].x = fmaf(p.x, z4.x, gw2[k].x); gw2[k].y = fmaf(p.y, z4.y, gw2[k].y);
                     gw2[k].z = fmaf(p.z, z4.z, gw2[k].z); gw2[k].w = fmaf(p.w, z4.w, gw2[k].w);
                     if (a == 1 && b == 1) {
@@ -239,64 +263,67 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         }
         __syncthreads();
 
-        // ---- phase 4: dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores --------
-#pragma unroll
-        for (int i = 0; i < G::TPW; ++i) {
-            const int tile = w1_tile0 + i;
-            const int mt = tile / G::NTO, nt = tile - mt * G::NTO;  // ci block, co block
-            const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + mt * 16 + l15;
-            const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + nt * 16 + l15;
+        // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
+        if (!(abl & 4)) {
+            const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + w1_mt * 16 + l15;
+            const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + w1_nt0 * 16 + l15;
+            const int ca = w1_mt * 16 + l15;
+            const float am = s_ci[ca], as_ = s_ci[CIN + ca], ab = s_ci[2 * CIN + ca];
 #pragma unroll 8
-            for (int s = 0; s < G::KSTEPS; ++s)
-                gw1[i] = mfma16(ap[4 * s * G::LSI], bp[4 * s * G::LSO], gw1[i]);
+            for (int s = 0; s < G::KSTEPS; ++s) {
+                const float ar = ap[4 * s * G::LSI];
+                const float av = bn_in ? bnrelu(ar, am, as_, ab) : ar;
+#pragma unroll
+                for (int i = 0; i < G::TPW; ++i)
+                    gw1[i] = mfma16(av, bp[4 * s * G::LSO + i * 16], gw1[i]);
+            }
         }
         f32x4 da[G::NTI];
 #pragma unroll
         for (int nt = 0; nt < G::NTI; ++nt) da[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
+        if (!(abl & 8)) {
             const float* prow = s_pb + (wid * 16 + l15) * G::LSO + g;
+            const float* wrow = s_w1 + g * G::WS + l15;
 #pragma unroll
             for (int s = 0; s < G::KSO; ++s) {
                 const float a = prow[4 * s];
 #pragma unroll
                 for (int nt = 0; nt < G::NTI; ++nt)
-                    da[nt] = mfma16(a, s_w1[(4 * s + g) * G::WS + nt * 16 + l15], da[nt]);
+                    da[nt] = mfma16(a, wrow[4 * s * G::WS + nt * 16], da[nt]);
             }
         }
         __syncthreads();  // every wave is done reading s_a for dW1
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ip = wid * 16 + 4 * g + r;
+        for (int nt = 0; nt < G::NTI; ++nt) {
+            const int c = nt * 16 + l15;
+            const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
 #pragma unroll
-            for (int nt = 0; nt < G::NTI; ++nt) {
-                float* ap = s_a + ip * G::LSI + nt * 16 + l15;
-                const float v = da[nt][r];
-                *ap = bn_in ? (*ap > 0.0f ? v : 0.0f) : v;   // ReLU mask of the input transform
+            for (int r = 0; r < 4; ++r) {
+                const int ip = wid * 16 + 4 * g + r;
+                float* ap = s_a + ip * G::LSI + c;
+                float v = da[nt][r];
+                if (bn_in) {
+                    const float xr = *ap;
+                    const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+                    v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? v : 0.0f;   // ReLU mask
+                    bst[nt] += v;
+                    bst[G::NTI + nt] = fmaf(v, (xr - cm) * ci, bst[G::NTI + nt]);
+                }
+                *ap = v;
             }
         }
         __syncthreads();
 
-        // ---- phase 5: dx store (coalesced) + BN-backward sums of the producer --------------------
-        if (d.dx) {
-            const float4 i_mean = *reinterpret_cast<float4*>(s_ci + ich4 * 4);
-            const float4 i_inv = *reinterpret_cast<float4*>(s_ci + 3 * CIN + ich4 * 4);
-            float* dxo = d.dx + (size_t)n * d.x_img_stride;
-            for (int q = tid; q < G::IP * G::C4I; q += BWD_THREADS) {
-                const int ip = q / G::C4I;
+        // ---- dx store (coalesced) + BN-backward sums of the producer ------------------------------
+        if (d.dx && !(abl & 16)) {
+            float* dxo = d.dx + (size_t)n * d.x_img_stride + ich4 * 4;
+#pragma unroll
+            for (int i = 0; i < G::NX; ++i) {
+                const int ip = (tid + BWD_THREADS * i) / G::C4I;
                 const int y = y0 + ip / TW, x = x0 + ip % TW;
                 if (y < H && x < W) {
-                    const size_t off = ((size_t)y * W + x) * CIN + ich4 * 4;
                     float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
-                    if (bn_in) {
-                        const float4 xr = *reinterpret_cast<const float4*>(xin + off);
-                        bst[0] += (double)v.x; bst[1] += (double)v.y;
-                        bst[2] += (double)v.z; bst[3] += (double)v.w;
-                        bst[4] += (double)(v.x * ((xr.x - i_mean.x) * i_inv.x));
-                        bst[5] += (double)(v.y * ((xr.y - i_mean.y) * i_inv.y));
-                        bst[6] += (double)(v.z * ((xr.z - i_mean.z) * i_inv.z));
-                        bst[7] += (double)(v.w * ((xr.w - i_mean.w) * i_inv.w));
-                    }
-                    float4* dst = reinterpret_cast<float4*>(dxo + off);
+                    float4* dst = reinterpret_cast<float4*>(dxo + ((size_t)y * W + x) * CIN);
                     if (d.accumulate_dx) {
                         const float4 o = *dst;
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -318,11 +345,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         if (w1_kslice == ks) {
 #pragma unroll
             for (int i = 0; i < G::TPW; ++i) {
-                const int tile = w1_tile0 + i;
-                const int mt = tile / G::NTO, nt = tile - mt * G::NTO;
+                const int nt = w1_nt0 + i;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s_gw1[(nt * 16 + l15) * CIN + mt * 16 + 4 * g + r] += gw1[i][r];
+                    s_gw1[(nt * 16 + l15) * CIN + w1_mt * 16 + 4 * g + r] += gw1[i][r];
             }
         }
         __syncthreads();
@@ -336,7 +362,6 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         float* my = red + tid * 16;
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
-            // slots of this pass: taps 4*pass .. 4*pass+3 (pass 2: tap 8, db1, db2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float4 v = make_float4(0, 0, 0, 0);
@@ -363,15 +388,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     }
     // (c) BN-backward sums of the producer: fp64 block reduce, one atomic per channel
     if (bn_in && d.dx && d.in_bn.bstats) {
-        double* red = reinterpret_cast<double*>(smem_raw);  // [BWD_THREADS][8]
+        double* red = reinterpret_cast<double*>(smem_raw);  // [BWD_THREADS][2*NTI]
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = bst[i];
+        for (int i = 0; i < 2 * G::NTI; ++i) red[tid * 2 * G::NTI + i] = (double)bst[i];
         __syncthreads();
         if (tid < 2 * CIN) {
             const int which = tid / CIN, c = tid % CIN;
-            const int q = c >> 2, k = (c & 3) + 4 * which;
+            const int nt = c >> 4, lc = c & 15;
             double v = 0.0;
-            for (int p = 0; p < BWD_THREADS / G::C4I; ++p) v += red[(p * G::C4I + q) * 8 + k];
+            for (int p = 0; p < BWD_THREADS / 16; ++p)      // all (wave, g) pairs holding channel c
+                v += red[(p * 16 + lc) * 2 * G::NTI + which * G::NTI + nt];
             atomic_add_f64(d.in_bn.bstats + which * CIN + c, v);
         }
     }

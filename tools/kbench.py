@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--prof', action='store_true')
+    ap.add_argument('--ablate', action='store_true')
     a = ap.parse_args()
     N = a.n
     cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
@@ -91,6 +92,12 @@ def main():
         d.wgrad_partials, d.wgrad_blocks = part.data_ptr(), blocks
         lib = L.load()
         t = timeit(lambda: L.check(lib.yunet_dp_bwd(C.byref(d), K._stream()), 'bwd'), a.reps)
+        if a.ablate:
+            for m in (1, 2, 4, 8, 16, 32, 63):
+                d.prof = m
+                tt = timeit(lambda: L.check(lib.yunet_dp_bwd(C.byref(d), K._stream()), 'bwd'), a.reps)
+                print(f'   ablate mask {m:2d}: {tt:.4f} ms (full {t:.4f})')
+            d.prof = None
         by = px * (2 * ci + co) * 4
         print(f'{name:8s} bwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s  {t * 1e-3 * 2.4e9 * 256 / px:7.1f} CUcyc/px')
         out = torch.empty(part.shape[1], device=DEV)
