@@ -585,10 +585,7 @@ class YuNetEngine:
         self.stage_gt(plan, gt_bboxes, gt_keypointss)
         plan.set_img(img)
         self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')
-        if self.world_size > 1:
-            # reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74): each rank holds
-            # num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound.
-            torch.distributed.all_reduce(plan.norm[0:1], group=self.process_group)
+        self.reduce_num_pos(plan.norm)
         self._exec(plan.c_fwd_b, 'yunet_exec(fwd_b)')
         self.params.num_batches_tracked += 1
         return plan.losses
@@ -601,6 +598,12 @@ class YuNetEngine:
             vec = [s[0]] + [s[1]] * 4 + [s[2]] + [s[3]] * 10
             plan.dy_scale.copy_(torch.tensor(vec, dtype=torch.float32), non_blocking=True)
         self._exec(plan.c_bwd, 'yunet_exec(bwd)')
+
+    def reduce_num_pos(self, norm):
+        """reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74, yunet_head.py:493-497):
+        every rank holds num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound."""
+        if self.world_size > 1:
+            torch.distributed.all_reduce(norm[0:1], group=self.process_group)
 
     def allreduce_grads(self, async_op=False):
         """DDP gradient mean: ONE collective over the flat 303 KB (n) / 218 KB (s) buffer."""

@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the N>1 path of the engine -- the flat gradient all-reduce, the
+num_pos reduce_mean, the batched logging all-reduce -- against the reference's formulas
+(mmdet/core/utils/dist_utils.py:68-74, mmdet/models/detectors/base.py:210-215)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import yunet_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import yunet_amd
+    import yunet_amd.engine as E
+    torch.manual_seed(1234 + rank)
+    eng = E.YuNetEngine(O.yunet_arch('s'), 'cpu', world_size=world, process_group=None)
+    # (1) gradient mean over ranks: ONE all-reduce of the flat buffer
+    g_local = torch.randn(eng.layout.numel)
+    eng.params.grad.copy_(g_local)
+    eng.allreduce_grads()
+    eng.params.grad.div_(world)
+    gathered = [torch.zeros_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    ok_grad = torch.allclose(eng.params.grad, sum(gathered) / world, atol=1e-6)
+    # (2) reduce_mean(num_pos): every rank contributes num_pos/world, SUM
+    npos = torch.tensor([17.0, 4.0])[rank]
+    norm = torch.tensor([float(npos) / world, 0.0, float(npos), 0.0])
+    eng.reduce_num_pos(norm)
+    ok_norm = abs(float(norm[0]) - (17.0 + 4.0) / world) < 1e-6 and float(norm[2]) == float(npos)
+    # (3) _parse_losses: log_vars are world-averaged, the loss used for backward is local
+    cfg = yunet_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'configs', 'yunet_s.py'))
+    m = yunet_amd.build_detector(cfg.model)
+    losses = dict(loss_cls=torch.tensor(1.0 + rank), loss_bbox=torch.tensor(2.0),
+                  loss_obj=torch.tensor(3.0 * (rank + 1)), loss_kps=torch.tensor(0.5))
+    loss, lv = m._parse_losses(losses)
+    ok_log = abs(float(loss) - sum(float(v) for v in losses.values())) < 1e-6 and \
+        abs(lv['loss_cls'] - 1.5) < 1e-6 and abs(lv['loss_obj'] - 4.5) < 1e-6 and \
+        abs(lv['loss'] - (6.5 + 10.5) / 2) < 1e-6
+    # (4) the wrapper starts every rank from rank 0's weights
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(float(rank))
+    w = YuNetDistributedDataParallel(m)
+    first = next(m.parameters()).detach().clone()
+    got = [torch.zeros_like(first) for _ in range(world)]
+    dist.all_gather(got, first)
+    ok_bcast = torch.equal(got[0], got[1]) and w.module._world == world
+    out[rank] = (ok_grad, ok_norm, ok_log, ok_bcast)
+    dist.destroy_process_group()
+
+
+def test_world_size_2_collectives():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        assert all(out[r]), (r, out[r])

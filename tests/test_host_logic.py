@@ -1,0 +1,156 @@
+"""CPU: host-side mirror of the reference interface -- registry/config, module surface,
+flat parameter layout, plan construction, LR schedule, synthetic data."""
+import math
+import os
+
+import pytest
+import torch
+
+import yunet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(kind):
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', f'yunet_{kind}.py'))
+    return yunet_amd.build_detector(cfg.model), cfg
+
+
+@pytest.mark.parametrize('kind,n_params,n_tensors', [('n', 75856, 154), ('s', 54608, 136)])
+def test_model_surface(kind, n_params, n_tensors):
+    """Parameter count / names / shapes are the checkpoint contract (README.md:146-147)."""
+    m, cfg = build(kind)
+    assert sum(p.numel() for p in m.parameters()) == n_params
+    assert len(list(m.parameters())) == n_tensors
+    ref = O.init_state(O.yunet_arch(kind))
+    sd = m.state_dict()
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    assert m.arch() == {**O.yunet_arch(kind)}
+    # reference init: bias 0.02, BN gamma 1 / beta 0 (yunet_backbone.py:21-31)
+    assert float(sd['backbone.model0.conv1.bias'][0]) == pytest.approx(0.02)
+    assert float(sd['neck.lateral_convs.1.bn.weight'][3]) == 1.0
+
+
+def test_registry_names_and_errors():
+    import yunet_amd
+    for name in ('YuNet', 'YuNetBackbone', 'TFPN', 'YuNet_Head', 'CrossEntropyLoss', 'EIoULoss',
+                 'DIoULoss', 'SmoothL1Loss'):
+        assert yunet_amd.MODELS.get(name) is not None, name
+    assert yunet_amd.BBOX_ASSIGNERS.get('SimOTAAssigner') is not None
+    assert yunet_amd.PRIOR_GENERATORS.get('MlvlPointGenerator') is not None
+    with pytest.raises(KeyError):
+        yunet_amd.build_detector(dict(type='NoSuchDetector'))
+    with pytest.raises(TypeError):
+        yunet_amd.build_from_cfg(dict(foo=1), yunet_amd.MODELS)
+    with pytest.raises(NotImplementedError):
+        yunet_amd.build_assigner(dict(type='SimOTAAssigner', candidate_topk=5))
+    m, _ = build('s')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.forward_train(torch.zeros(1, 3, 160, 160), [{}], [torch.zeros(1, 4)], [torch.zeros(1)],
+                        [torch.zeros(1, 5, 3)])
+
+
+def test_config_overrides_and_cli_surface():
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'yunet_n.py'))
+    cfg.merge_from_dict({'optimizer.lr': 0.02, 'data.samples_per_gpu': 8})
+    assert cfg.optimizer.lr == 0.02 and cfg.data.samples_per_gpu == 8
+    assert cfg.model.bbox_head.loss_bbox.type == 'EIoULoss'
+    assert cfg.dist_params.backend == 'nccl'
+
+
+def test_flat_layout_is_a_bijection():
+    import yunet_amd.engine as E
+    for kind in ('n', 's'):
+        m, _ = build(kind)
+        lay = E.ParamLayout(m.arch())
+        names = [k for k, _ in m.named_parameters()]
+        assert set(lay.entries) == set(names)
+        cover = torch.zeros(lay.numel, dtype=torch.int32)
+        for k, (off, shape) in lay.entries.items():
+            cover[off:off + math.prod(shape)] += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1       # no gap, no overlap
+        # fused head rows: cls | bbox | obj | kps
+        off0 = lay.units['head.0']['off']
+        assert lay.entries['bbox_head.multi_level_cls.0.conv1.weight'][0] == off0
+        assert lay.entries['bbox_head.multi_level_bbox.0.conv1.weight'][0] == off0 + 64
+        assert lay.entries['bbox_head.multi_level_obj.0.conv1.weight'][0] == off0 + 5 * 64
+        assert lay.entries['bbox_head.multi_level_kps.0.conv1.weight'][0] == off0 + 6 * 64
+
+
+def test_plan_builds_on_cpu_and_orders_accumulation():
+    """Op lists can be built without a GPU (pointers only).  Taps consumed twice (pool + TFPN)
+    must have exactly one overwriting and one accumulating backward writer."""
+    import yunet_amd._lib as L
+    import yunet_amd.engine as E
+    for kind, h in (('n', 320), ('s', 160)):
+        eng = E.YuNetEngine(O.yunet_arch(kind), 'cpu')
+        plan = eng.get_plan(2, h, h, 3)
+        assert plan.P == sum((h // s) ** 2 for s in (8, 16, 32))
+        ops = plan.fwd_a + plan.fwd_b + plan.bwd
+        assert all(1 <= op.opcode <= 17 for op in ops)
+        n_dp = sum(1 for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
+        assert n_dp == len(E.ParamLayout.dp_units(eng.arch)) + 3
+        assert sum(1 for op in plan.bwd if op.opcode == L.OP_DP_BWD) == n_dp
+        writers = {}
+        for op in plan.bwd:
+            if op.opcode == L.OP_DP_BWD:
+                writers.setdefault(op.dp.dx, []).append(op.dp.accumulate_dx)
+            elif op.opcode == L.OP_POOL_BWD:
+                writers.setdefault(op.p[2], []).append(op.i[4])
+            elif op.opcode == L.OP_UPADD_BWD:
+                writers.setdefault(op.p[3], []).append(op.i[4])
+                writers.setdefault(op.p[4], []).append(op.i[5])
+        multi = [w for w in writers.values() if len(w) > 1]
+        assert len(multi) == 4                      # two backbone taps + two lateral outputs
+        for w in writers.values():
+            assert w[0] == 0 and all(a == 1 for a in w[1:])
+    with pytest.raises(ValueError, match='multiples of 32'):
+        E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(1, 100, 100, 1)
+
+
+def test_lr_schedule_matches_mmcv_semantics():
+    """regular lr = 0.01*0.1^(#steps<=epoch); linear warm-up over 1500 iters
+    from ratio 0.001; checkpoint optimizer lr after both steps is 1e-4."""
+    from yunet_amd.runner import StepLrWarmup
+    s = StepLrWarmup(0.01, step=[400, 544], warmup='linear', warmup_iters=1500, warmup_ratio=0.001)
+    assert s.lr_at(0, 0) == pytest.approx(0.01 * 0.001)
+    assert s.lr_at(0, 750) == pytest.approx(0.01 * (1 - 0.5 * 0.999))
+    assert s.lr_at(3, 1500) == pytest.approx(0.01)
+    assert s.lr_at(400, 10 ** 6) == pytest.approx(0.001)
+    assert s.lr_at(560, 10 ** 6) == pytest.approx(1e-4)
+
+
+def test_synthetic_batches_are_deterministic_and_well_formed():
+    import yunet_amd.synthetic as S
+    a, b = S.make_batch(6, 320, 320, 99), S.make_batch(6, 320, 320, 99)
+    assert torch.equal(a['img'], b['img'])
+    assert float(a['img'].min()) >= 0 and float(a['img'].max()) < 255
+    for ga, gb_, ka in zip(a['gt_bboxes'], b['gt_bboxes'], a['gt_keypointss']):
+        assert torch.equal(ga, gb_) and 1 <= ga.shape[0] <= S.MAX_GT
+        assert (ga[:, 2] > ga[:, 0]).all() and (ga[:, 3] > ga[:, 1]).all()
+        assert float(ga.min()) >= 0 and float(ga[:, 2].max()) <= 320
+        assert ka.shape[1:] == (5, 3) and set(ka[..., 2].unique().tolist()) <= {0.0, 1.0}
+    pad = a['gt_bboxes'].padded
+    for i, g in enumerate(a['gt_bboxes']):
+        assert torch.equal(pad[i, :g.shape[0]], g) and int(a['gt_bboxes'].counts[i]) == g.shape[0]
+    assert sum(S.WIDER_VAL_FACES_HIST) == 3226
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from yunet_amd.optim import FusedSGD
+    from yunet_amd import runner as R
+    m, _ = build('s')
+    opt = FusedSGD(m, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    path = os.path.join(tmp_path, 'ck.pth')
+    R.save_checkpoint(m, opt, path, dict(epoch=3, iter=77))
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ck) == {'meta', 'state_dict', 'optimizer'}      # reference checkpoint format
+    m2, _ = build('s')
+    meta = R.load_checkpoint(m2, path)
+    assert meta['epoch'] == 3
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
