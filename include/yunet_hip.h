@@ -90,6 +90,9 @@ int yunet_stem_bwd(const float* img, const float* z, const float* dy, const Yune
 
 int yunet_dp_fwd(const YunetDP* d, void* stream);
 int yunet_dp_bwd(const YunetDP* d, void* stream);
+/* rows of wgrad_partials (= persistent grid) yunet_dp_bwd / yunet_stem_bwd use for a shape */
+int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
+int yunet_stem_bwd_blocks(int N, int H, int W);
 
 /* F.max_pool2d(relu(bn(z)), 2)  (yunet_backbone.py:39-40).  out [N,H/2,W/2,C]. */
 int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
@@ -115,6 +118,14 @@ int yunet_bn_update_running(const double* stats, float* running_mean, float* run
 /* Final BN parameter gradients: d(gamma) = bstats[C:2C], d(beta) = bstats[0:C]. */
 int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C,
                         int accumulate, void* stream);
+
+/* All BatchNorm layers of the model in ONE launch.  table (device, int32 [n,6]) rows:
+ * {stats offset (doubles, into stats_base), C, count, running offset (floats),
+ *  dgamma offset, dbeta offset (floats, into grad_base)}.
+ * mode 0: running_mean/var update from the forward sums at stats_base + off;
+ * mode 1: d(gamma), d(beta) from the backward sums at stats_base + off. */
+int yunet_bn_batch(const int32_t* table, int n, const double* stats_base, float* running_mean,
+                   float* running_var, float momentum, float* grad_base, int mode, void* stream);
 
 /* out[j] (+)= sum_b partials[b, j]  for j < width, deterministic order. */
 int yunet_reduce_partials(const float* partials, int blocks, int width, float* out,
@@ -194,7 +205,7 @@ enum {
     YUNET_OP_POOL_FWD, YUNET_OP_POOL_BWD, YUNET_OP_UPADD_FWD, YUNET_OP_UPADD_BWD,
     YUNET_OP_BN_RUNNING, YUNET_OP_BN_PARAM_GRAD, YUNET_OP_REDUCE_PARTIALS,
     YUNET_OP_ASSIGN, YUNET_OP_LOSS_NORM, YUNET_OP_LOSS, YUNET_OP_LOSS_FINALIZE,
-    YUNET_OP_SGD, YUNET_OP_MEMSET
+    YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH
 };
 typedef struct YunetOp {
     int32_t opcode;

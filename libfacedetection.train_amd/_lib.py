@@ -16,7 +16,7 @@ T_IDENTITY, T_BNRELU = 0, 1
 BOX_EIOU, BOX_DIOU = 0, 1
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
- OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET) = range(1, 18)
+ OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH) = range(1, 19)
 
 
 class YunetBN(C.Structure):
@@ -62,6 +62,8 @@ _SIGNATURES = {
                        [C.c_int] * 5 + [C.c_void_p]),
     'yunet_dp_fwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
     'yunet_dp_bwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
+    'yunet_dp_bwd_blocks': (C.c_int, [C.c_int] * 5),
+    'yunet_stem_bwd_blocks': (C.c_int, [C.c_int] * 3),
     'yunet_pool_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 4 +
                        [C.c_void_p]),
     'yunet_pool_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p] +
@@ -74,6 +76,8 @@ _SIGNATURES = {
     'yunet_bn_update_running': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float,
                                                              C.c_void_p]),
     'yunet_bn_param_grad': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
+    'yunet_bn_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                 C.c_void_p, C.c_int, C.c_void_p]),
     'yunet_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p]),
     'yunet_assign': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +

@@ -20,7 +20,41 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// every BatchNorm layer of the model in one launch (one workgroup per layer)
+__global__ void bn_batch_kernel(const int32_t* __restrict__ table, const double* __restrict__ stats_base,
+                                float* __restrict__ rm, float* __restrict__ rv, float momentum,
+                                float* __restrict__ grad_base, int mode) {
+    const int32_t* t = table + blockIdx.x * 6;
+    const int C = t[1], count = t[2];
+    const double* st = stats_base + t[0];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (mode == 0) {
+            const double inv = 1.0 / (double)count;
+            const double mean = st[c] * inv;
+            double var = st[C + c] * inv - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+            float* m = rm + t[3];
+            float* v = rv + t[3];
+            m[c] = (1.0f - momentum) * m[c] + momentum * (float)mean;
+            v[c] = (1.0f - momentum) * v[c] + momentum * (float)unb;
+        } else {
+            grad_base[t[5] + c] = (float)st[c];        // d(beta)  = sum dy
+            grad_base[t[4] + c] = (float)st[C + c];    // d(gamma) = sum dy * xhat
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int yunet_bn_batch(const int32_t* table, int n, const double* stats_base,
+                              float* running_mean, float* running_var, float momentum,
+                              float* grad_base, int mode, void* stream) {
+    if (n < 1) return YUNET_EINVAL;
+    hipLaunchKernelGGL(bn_batch_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, table, stats_base,
+                       running_mean, running_var, momentum, grad_base, mode);
+    return hip_status();
+}
 
 extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
                               const float* lr_dev, float momentum, float weight_decay,
@@ -113,6 +147,10 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
                 rc = -(int)hipMemsetAsync(o.p[0], 0, n, (hipStream_t)stream);
                 break;
             }
+            case YUNET_OP_BN_BATCH:
+                rc = yunet_bn_batch((const int32_t*)o.p[0], o.i[0], (const double*)o.p[1], (float*)o.p[2],
+                                    (float*)o.p[3], o.f[0], (float*)o.p[4], o.i[1], stream);
+                break;
             default:
                 return YUNET_EOPCODE;
         }

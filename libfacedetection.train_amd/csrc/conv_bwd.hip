@@ -45,7 +45,8 @@ struct BwdGeom {
     static constexpr size_t WORK = (size_t)WORK_F * 4;
     static constexpr size_t WORKB = WORK > RED1 ? (WORK > RED2 ? WORK : RED2) : (RED1 > RED2 ? RED1 : RED2);
     static constexpr size_t SMEM = WORKB + (size_t)PAR_F * 4;
-    static_assert(IP % 16 == 0 && IMT == BWD_WAVES, "one 16-pixel M tile per wave");
+    static constexpr int MPW = IMT / BWD_WAVES;     // 16-pixel M tiles per wave
+    static_assert(IP % 16 == 0 && IMT % BWD_WAVES == 0, "whole M tiles per wave");
     static_assert(PG % TW == 0 && IP % PG == 0, "VALU mapping");
     static_assert(BWD_THREADS % C4I == 0 && BWD_THREADS % C4O == 0, "load mapping");
     static_assert((IP * C4I) % BWD_THREADS == 0, "x load mapping");
@@ -208,27 +209,31 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
 
         // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
         if (!(abl & 1)) {
-            f32x4 acc[G::NTO];
+#pragma unroll 1
+            for (int mi = 0; mi < G::MPW; ++mi) {
+                const int mt = wid * G::MPW + mi;
+                f32x4 acc[G::NTO];
 #pragma unroll
-            for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* arow = s_a + (wid * 16 + l15) * G::LSI + g;
-            const float* brow = s_w1 + l15 * G::WS + g;
+                for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* arow = s_a + (mt * 16 + l15) * G::LSI + g;
+                const float* brow = s_w1 + l15 * G::WS + g;
 #pragma unroll
-            for (int s = 0; s < G::KSI; ++s) {
-                const int c = 4 * s + g;
-                const float ar = arow[4 * s];
-                const float a = bn_in ? bnrelu(ar, s_ci[c], s_ci[CIN + c], s_ci[2 * CIN + c]) : ar;
+                for (int s = 0; s < G::KSI; ++s) {
+                    const int c = 4 * s + g;
+                    const float ar = arow[4 * s];
+                    const float a = bn_in ? bnrelu(ar, s_ci[c], s_ci[CIN + c], s_ci[2 * CIN + c]) : ar;
 #pragma unroll
-                for (int nt = 0; nt < G::NTO; ++nt)
-                    acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
-            }
+                    for (int nt = 0; nt < G::NTO; ++nt)
+                        acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ip = wid * 16 + 4 * g + r;
-                const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+                for (int r = 0; r < 4; ++r) {
+                    const int ip = mt * 16 + 4 * g + r;
+                    const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
 #pragma unroll
-                for (int nt = 0; nt < G::NTO; ++nt)
-                    s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
+                    for (int nt = 0; nt < G::NTO; ++nt)
+                        s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
+                }
             }
         }
         __syncthreads();
@@ -278,18 +283,23 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                     gw1[i] = mfma16(av, bp[4 * s * G::LSO + i * 16], gw1[i]);
             }
         }
-        f32x4 da[G::NTI];
+        f32x4 da[G::MPW][G::NTI];
 #pragma unroll
-        for (int nt = 0; nt < G::NTI; ++nt) da[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < G::MPW; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(abl & 8)) {
-            const float* prow = s_pb + (wid * 16 + l15) * G::LSO + g;
-            const float* wrow = s_w1 + g * G::WS + l15;
 #pragma unroll
-            for (int s = 0; s < G::KSO; ++s) {
-                const float a = prow[4 * s];
+            for (int mi = 0; mi < G::MPW; ++mi) {
+                const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + g;
+                const float* wrow = s_w1 + g * G::WS + l15;
 #pragma unroll
-                for (int nt = 0; nt < G::NTI; ++nt)
-                    da[nt] = mfma16(a, wrow[4 * s * G::WS + nt * 16], da[nt]);
+                for (int s = 0; s < G::KSO; ++s) {
+                    const float a = prow[4 * s];
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt)
+                        da[mi][nt] = mfma16(a, wrow[4 * s * G::WS + nt * 16], da[mi][nt]);
+                }
             }
         }
         __syncthreads();  // every wave is done reading s_a for dW1
@@ -298,19 +308,21 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             const int c = nt * 16 + l15;
             const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ip = wid * 16 + 4 * g + r;
-                float* ap = s_a + ip * G::LSI + c;
-                float v = da[nt][r];
-                if (bn_in) {
-                    const float xr = *ap;
-                    const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
-                    v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? v : 0.0f;   // ReLU mask
-                    bst[nt] += v;
-                    bst[G::NTI + nt] = fmaf(v, (xr - cm) * ci, bst[G::NTI + nt]);
+            for (int mi = 0; mi < G::MPW; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ip = (wid * G::MPW + mi) * 16 + 4 * g + r;
+                    float* ap = s_a + ip * G::LSI + c;
+                    float v = da[mi][nt][r];
+                    if (bn_in) {
+                        const float xr = *ap;
+                        const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+                        v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? v : 0.0f;   // ReLU mask
+                        bst[nt] += v;
+                        bst[G::NTI + nt] = fmaf(v, (xr - cm) * ci, bst[G::NTI + nt]);
+                    }
+                    *ap = v;
                 }
-                *ap = v;
-            }
         }
         __syncthreads();
 
@@ -429,7 +441,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dy, YunetBN bn,
                                                        float* __restrict__ partials, int N, int H,
                                                        int W) {
-    constexpr int PH = 2 * SB_TH + 1, PW = 2 * SB_TW + 1, PWS = PW + 1;
+    constexpr int PH = 2 * SB_TH + 1;
+    constexpr int PW4 = (2 * SB_TW + 8) / 4;            // aligned float4 per patch row
+    constexpr int PWS = PW4 * 4 + 1;                    // odd LDS row stride
+    constexpr int NLD = (3 * PH * PW4 + 255) / 256;
     constexpr int DZS = 20;
     constexpr int PATCH_F = ((3 * PH * PWS + 3) / 4) * 4;
     constexpr int DZT_F = SB_TH * SB_TW * DZS;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         tok[k] = t < 27;
         const int tt = tok[k] ? t : 0;
         const int ci = tt / 9, ky = (tt % 9) / 3, kx = tt % 3;
-        toff[k] = ci * PH * PWS + ky * PWS + kx;
+        toff[k] = ci * PH * PWS + ky * PWS + kx + 3;   // patch col 0 = image col 2*x0 - 4
     }
     float4 acc[7];
 #pragma unroll
@@ -478,14 +493,34 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const int r = t - n * tiles_x * tiles_y;
         const int y0 = (r / tiles_x) * SB_TH, x0 = (r % tiles_x) * SB_TW;
         __syncthreads();
-        for (int i = tid; i < 3 * PH * PW; i += 256) {
-            const int ci = i / (PH * PW), q = i - ci * PH * PW;
-            const int py = q / PW, px = q - py * PW;
-            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
-            float v = 0.0f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = img[(((size_t)n * 3 + ci) * H + iy) * W + ix];
-            s_patch[ci * PH * PWS + py * PWS + px] = v;
+        {
+            float4 ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + 256 * k;
+                const int rowi = i / PW4, c4 = i - rowi * PW4;
+                const int ci = rowi / PH, py = rowi - ci * PH;
+                const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 4 + 4 * c4;
+                ld[k] = make_float4(0, 0, 0, 0);
+                if (rowi < 3 * PH && iy >= 0 && iy < H && ix >= 0 && ix + 3 < W)
+                    ld[k] = *reinterpret_cast<const float4*>(img + (((size_t)n * 3 + ci) * H + iy) * W + ix);
+                else if (rowi < 3 * PH && iy >= 0 && iy < H) {
+                    const float* src = img + (((size_t)n * 3 + ci) * H + iy) * W;
+                    if (ix + 0 >= 0 && ix + 0 < W) ld[k].x = src[ix + 0];
+                    if (ix + 1 >= 0 && ix + 1 < W) ld[k].y = src[ix + 1];
+                    if (ix + 2 >= 0 && ix + 2 < W) ld[k].z = src[ix + 2];
+                    if (ix + 3 >= 0 && ix + 3 < W) ld[k].w = src[ix + 3];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + 256 * k;
+                const int rowi = i / PW4, c4 = i - rowi * PW4;
+                if (rowi < 3 * PH) {
+                    float* dst = s_patch + rowi * PWS + 4 * c4;
+                    dst[0] = ld[k].x; dst[1] = ld[k].y; dst[2] = ld[k].z; dst[3] = ld[k].w;
+                }
+            }
         }
         for (int q = tid; q < SB_TH * SB_TW * 4; q += 256) {
             const int pix = q >> 2;
@@ -744,11 +779,30 @@ inline int ew_grid(long long total) {
 
 }  // namespace
 
+#define DP_BWD_MAX_BLOCKS 256     // 512 threads, up to 138 KB LDS: one workgroup per CU
+#define STEM_BWD_MAX_BLOCKS 768   // 256 threads, 35 KB LDS: three per CU
+static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
+    return cin == 16 && cout == 16 && W >= 64 && H >= 32;
+}
+extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
+    const int th = dp_bwd_big_tile(H, W, cin, cout) ? 16 : 8, tw = th * 2;
+    const long long tiles = (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
+    return (int)(tiles < DP_BWD_MAX_BLOCKS ? tiles : DP_BWD_MAX_BLOCKS);
+}
+extern "C" int yunet_stem_bwd_blocks(int N, int H, int W) {
+    const long long tiles = (long long)N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
+    return (int)(tiles < STEM_BWD_MAX_BLOCKS ? tiles : STEM_BWD_MAX_BLOCKS);
+}
+
 extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!d->wgrad_partials || d->wgrad_blocks < 1) return YUNET_EINVAL;
+    if (!d->wgrad_partials ||
+        d->wgrad_blocks != yunet_dp_bwd_blocks(d->N, d->H, d->W, d->cin, d->cout))
+        return YUNET_EINVAL;   // the partial buffer must have exactly the rows the grid writes
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
+    if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))
+        return launch_dp_bwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)
@@ -763,7 +817,8 @@ extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
 extern "C" int yunet_stem_bwd(const float* img, const float* z, const float* dy, const YunetBN* bn,
                               float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
                               void* stream) {
-    if (cmid != 16 || (H & 1) || (W & 1) || wgrad_blocks < 1) return YUNET_EINVAL;
+    if (cmid != 16 || (H & 1) || (W & 1) || wgrad_blocks != yunet_stem_bwd_blocks(N, H, W))
+        return YUNET_EINVAL;
     const int tiles = N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > wgrad_blocks) grid = wgrad_blocks;

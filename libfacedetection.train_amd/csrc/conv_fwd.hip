@@ -15,17 +15,23 @@ namespace {
 
 // ------------------------------------------------------------------------------- stem
 #define STEM_TW 32
-#define STEM_TH 8
-// one thread = one output pixel x 16 channels; the (2*TH+1)x(2*TW+1)x3 input patch is staged
-// in LDS from the NCHW image (coalesced along W).
+#define STEM_TH 16
+#define STEM_PX 2
+// 16x32 output tile per 256-thread workgroup; one thread = 2 consecutive output pixels of a
+// row x 16 channels (32 accumulators), so every weight read from LDS feeds 2 pixels.  The
+// input patch is staged from the NCHW image with 16-byte ALIGNED float4 loads: patch column j
+// holds image column 2*x0 - 4 + j (x0 is a multiple of 32, so 2*x0 - 4 is 16-byte aligned).
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b,
                                                        float* __restrict__ z,
                                                        double* __restrict__ stats, int N, int H,
                                                        int W) {
-    constexpr int PH = 2 * STEM_TH + 1, PW = 2 * STEM_TW + 1, PWS = PW + 1;
-    __shared__ float s_patch[3][PH][PWS];
+    constexpr int PH = 2 * STEM_TH + 1;                 // patch rows per channel
+    constexpr int PW4 = (2 * STEM_TW + 8) / 4;          // float4 per patch row (aligned superset)
+    constexpr int PWS = PW4 * 4 + 1;                    // odd LDS row stride
+    constexpr int NLD = (3 * PH * PW4 + 255) / 256;     // float4 loads per thread per tile
+    __shared__ float s_patch[3 * PH * PWS];
     __shared__ __attribute__((aligned(16))) float s_w[27][16];
     __shared__ double s_red[4][32];
     const int tid = threadIdx.x;
@@ -43,53 +49,96 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 
     const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, tiles_y = (Ho + STEM_TH - 1) / STEM_TH;
     const int ntiles = N * tiles_x * tiles_y;
-    const int tx = tid % STEM_TW, ty = tid / STEM_TW;
+    const int cg = tid & 15, ty = tid >> 4;     // column group (STEM_PX pixels), row
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int n = t / (tiles_x * tiles_y);
         const int r = t - n * tiles_x * tiles_y;
         const int y0 = (r / tiles_x) * STEM_TH, x0 = (r % tiles_x) * STEM_TW;
         __syncthreads();
-        for (int i = tid; i < 3 * PH * PW; i += 256) {
-            const int ci = i / (PH * PW), q = i - ci * PH * PW;
-            const int py = q / PW, px = q - py * PW;
-            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
-            float v = 0.0f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = img[(((size_t)n * 3 + ci) * H + iy) * W + ix];
-            s_patch[ci][py][px] = v;
+        {
+            float4 ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + 256 * k;
+                const int rowi = i / PW4, c4 = i - rowi * PW4;
+                const int ci = rowi / PH, py = rowi - ci * PH;
+                const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 4 + 4 * c4;
+                ld[k] = make_float4(0, 0, 0, 0);
+                if (rowi < 3 * PH && iy >= 0 && iy < H && ix >= 0 && ix + 3 < W)
+                    ld[k] = *reinterpret_cast<const float4*>(img + (((size_t)n * 3 + ci) * H + iy) * W + ix);
+                else if (rowi < 3 * PH && iy >= 0 && iy < H) {      // row edge: element-wise
+                    const float* src = img + (((size_t)n * 3 + ci) * H + iy) * W;
+                    if (ix + 0 >= 0 && ix + 0 < W) ld[k].x = src[ix + 0];
+                    if (ix + 1 >= 0 && ix + 1 < W) ld[k].y = src[ix + 1];
+                    if (ix + 2 >= 0 && ix + 2 < W) ld[k].z = src[ix + 2];
+                    if (ix + 3 >= 0 && ix + 3 < W) ld[k].w = src[ix + 3];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + 256 * k;
+                const int rowi = i / PW4, c4 = i - rowi * PW4;
+                if (rowi < 3 * PH) {
+                    float* dst = s_patch + rowi * PWS + 4 * c4;
+                    dst[0] = ld[k].x; dst[1] = ld[k].y; dst[2] = ld[k].z; dst[3] = ld[k].w;
+                }
+            }
         }
         __syncthreads();
-        const int oy = y0 + ty, ox = x0 + tx;
-        float acc[16];
+        float acc[STEM_PX][16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = bias[c];
+        for (int p = 0; p < STEM_PX; ++p)
 #pragma unroll
+            for (int c = 0; c < 16; ++c) acc[p][c] = bias[c];
+#pragma unroll 1
         for (int ci = 0; ci < 3; ++ci)
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* prow = s_patch + (ci * PH + 2 * ty + ky) * PWS + 2 * STEM_PX * cg + 3;
+                float pv[2 * STEM_PX + 1];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int j = 0; j < 2 * STEM_PX + 1; ++j) pv[j] = prow[j];
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float v = s_patch[ci][2 * ty + ky][2 * tx + kx];
                     const float4* wr = reinterpret_cast<const float4*>(s_w[ci * 9 + ky * 3 + kx]);
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) {
                         const float4 ww = wr[c4];
-                        acc[c4 * 4 + 0] = fmaf(v, ww.x, acc[c4 * 4 + 0]);
-                        acc[c4 * 4 + 1] = fmaf(v, ww.y, acc[c4 * 4 + 1]);
-                        acc[c4 * 4 + 2] = fmaf(v, ww.z, acc[c4 * 4 + 2]);
-                        acc[c4 * 4 + 3] = fmaf(v, ww.w, acc[c4 * 4 + 3]);
+#pragma unroll
+                        for (int p = 0; p < STEM_PX; ++p) {
+                            const float v = pv[2 * p + kx];
+                            acc[p][c4 * 4 + 0] = fmaf(v, ww.x, acc[p][c4 * 4 + 0]);
+                            acc[p][c4 * 4 + 1] = fmaf(v, ww.y, acc[p][c4 * 4 + 1]);
+                            acc[p][c4 * 4 + 2] = fmaf(v, ww.z, acc[p][c4 * 4 + 2]);
+                            acc[p][c4 * 4 + 3] = fmaf(v, ww.w, acc[p][c4 * 4 + 3]);
+                        }
                     }
                 }
-        if (oy < Ho && ox < Wo) {
-            float4* dst = reinterpret_cast<float4*>(z + (((size_t)n * Ho + oy) * Wo + ox) * 16);
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4)
-                dst[c4] = make_float4(acc[c4 * 4], acc[c4 * 4 + 1], acc[c4 * 4 + 2], acc[c4 * 4 + 3]);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                ssum[c] += (double)acc[c];
-                ssq[c] += (double)acc[c] * (double)acc[c];
             }
+        const int oy = y0 + ty;
+        float ts[16], tq[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ts[c] = tq[c] = 0.0f;
+#pragma unroll
+        for (int p = 0; p < STEM_PX; ++p) {
+            const int ox = x0 + STEM_PX * cg + p;
+            if (oy < Ho && ox < Wo) {
+                float4* dst = reinterpret_cast<float4*>(z + (((size_t)n * Ho + oy) * Wo + ox) * 16);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+                    dst[c4] = make_float4(acc[p][c4 * 4], acc[p][c4 * 4 + 1], acc[p][c4 * 4 + 2],
+                                          acc[p][c4 * 4 + 3]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    ts[c] += acc[p][c];
+                    tq[c] = fmaf(acc[p][c], acc[p][c], tq[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            ssum[c] += (double)ts[c];
+            ssq[c] += (double)tq[c];
         }
     }
     // block reduction of the statistics: wave shuffles, then 4 waves through LDS

@@ -309,24 +309,30 @@ class Plan:
         self.fwd_b.append(self._op(L.OP_LOSS_FINALIZE, p=[self.loss_partials.data_ptr(),
                                                          self.losses.data_ptr()],
                                    i=[self.loss_blocks]))
-        # BN running statistics (nn.BatchNorm2d momentum 0.1)
-        for name in lay.bn_names:
-            b = self.bn[name]
-            o2 = fp.bn_offset[name]
+        # BN running statistics (nn.BatchNorm2d momentum 0.1) and, in backward, d(gamma)/d(beta)
+        # of ALL BatchNorm layers: one launch each, driven by a small device table
+        rows_f, rows_b = [], []
+        so = 0
+        for name, c in zip(lay.bn_names, fp.bn_channels):
             cnt = self.bn_count[name]
-            self.fwd_b.append(self._op(
-                L.OP_BN_RUNNING,
-                p=[b['stats'].data_ptr(), fp.running_mean.data_ptr() + 4 * o2,
-                   fp.running_var.data_ptr() + 4 * o2], i=[b['c'], cnt], f=[BN_MOMENTUM]))
+            g_off = lay.entries[name + '.weight'][0]
+            b_off = lay.entries[name + '.bias'][0]
+            rows_f.append([so, c, cnt, fp.bn_offset[name], g_off, b_off])
+            rows_b.append([2 * tot_c + so, c, cnt, fp.bn_offset[name], g_off, b_off])
+            so += 2 * c
+        self.bn_table_f = torch.tensor(rows_f, dtype=torch.int32).to(dev)
+        self.bn_table_b = torch.tensor(rows_b, dtype=torch.int32).to(dev)
+        self.fwd_b.append(self._op(
+            L.OP_BN_BATCH, p=[self.bn_table_f.data_ptr(), self.stats.data_ptr(),
+                              fp.running_mean.data_ptr(), fp.running_var.data_ptr(), None],
+            i=[len(rows_f), 0], f=[BN_MOMENTUM]))
 
         # ---- backward: reverse of the forward nodes
         for node in reversed(self.bwd_nodes):
             node()
-        for name in lay.bn_names:
-            b = self.bn[name]
-            self.bwd.append(self._op(L.OP_BN_PARAM_GRAD,
-                                     p=[b['bstats'].data_ptr(), b['dgamma'], b['dbeta']],
-                                     i=[b['c'], 0]))
+        self.bwd.append(self._op(
+            L.OP_BN_BATCH, p=[self.bn_table_b.data_ptr(), self.stats.data_ptr(), None, None,
+                              fp.grad.data_ptr()], i=[len(rows_b), 1], f=[0.0]))
         self.c_fwd_a = self._carray(self.fwd_a)
         self.c_fwd_b = self._carray(self.fwd_b)
         self.c_bwd = self._carray(self.bwd)
@@ -443,7 +449,7 @@ class Plan:
         op = self._op(L.OP_DP_FWD)
         op.dp = d
         self.fwd_a.append(op)
-        blocks = K.dp_grid(x.n, x.h, x.w)
+        blocks = K.dp_grid(x.n, x.h, x.w, u['cin'], u['cout'])
         width = K.dp_row_width(u['cin'], u['cout'])
         part = torch.empty(blocks, width, device=self.eng.device, dtype=torch.float32)
         self.keep.append(part)
@@ -619,6 +625,7 @@ class YuNetEngine:
         n, _, h, w = img.shape
         plan = self.get_plan(n, h, w, 1)
         self.plan = plan
+        self._img = img          # the backward op list reads the image again (stem wgrad)
         plan.set_img(img)
         plan.gt_count.zero_()
         self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')

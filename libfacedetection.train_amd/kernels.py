@@ -47,21 +47,13 @@ def conv_blocks():
     return L.load().yunet_conv_blocks()
 
 
-# Persistent grids of the backward kernels (= rows of their weight-gradient partials).
-# dp_bwd uses 512 threads and up to 138 KB of LDS: one workgroup per CU is resident, so 256
-# workgroups cover the chip; stem_bwd (256 threads, 34 KB) fits three per CU.
-DP_BWD_BLOCKS = 256
-STEM_BWD_BLOCKS = 768
-
-
-def dp_grid(n, h, w):
-    tiles = n * ((w + 15) // 16) * ((h + 7) // 8)
-    return min(tiles, DP_BWD_BLOCKS)
+def dp_grid(n, h, w, cin=64, cout=64):
+    """rows of the weight-gradient partial buffer (= persistent grid) of yunet_dp_bwd"""
+    return L.load().yunet_dp_bwd_blocks(n, h, w, cin, cout)
 
 
 def stem_grid(n, h, w):
-    tiles = n * ((w // 2 + 31) // 32) * ((h // 2 + 7) // 8)
-    return min(tiles, STEM_BWD_BLOCKS)
+    return L.load().yunet_stem_bwd_blocks(n, h, w)
 
 
 def dp_row_width(cin, cout):
@@ -142,7 +134,7 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
     d.dy_scale = dy_scale.data_ptr() if dy_scale is not None else None
     d.dx = dx.data_ptr() if dx is not None else None
     d.accumulate_dx = int(accumulate_dx)
-    blocks = dp_grid(n, h, w)
+    blocks = dp_grid(n, h, w, cin, cout)
     width = dp_row_width(cin, cout)
     part = torch.empty(blocks, width, device=x.device, dtype=torch.float32)
     d.wgrad_partials, d.wgrad_blocks = part.data_ptr(), blocks

@@ -91,7 +91,7 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
         plan = eng.get_plan(2, h, h, 3)
         assert plan.P == sum((h // s) ** 2 for s in (8, 16, 32))
         ops = plan.fwd_a + plan.fwd_b + plan.bwd
-        assert all(1 <= op.opcode <= 17 for op in ops)
+        assert all(1 <= op.opcode <= 18 for op in ops)
         n_dp = sum(1 for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
         assert n_dp == len(E.ParamLayout.dp_units(eng.arch)) + 3
         assert sum(1 for op in plan.bwd if op.opcode == L.OP_DP_BWD) == n_dp

@@ -83,7 +83,7 @@ def main():
         dx = torch.empty_like(x)
         if out_bn is not None:
             out_bn.stats = stats_like(z)
-        blocks = K.dp_grid(N, h, w)
+        blocks = K.dp_grid(N, h, w, ci, co)
         part = torch.empty(blocks, K.dp_row_width(ci, co), device=DEV)
         import ctypes as C
         import yunet_amd._lib as L
