@@ -23,6 +23,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //   y = (x - mean) * scale + beta,  scale = gamma * invstd,  invstd = 1/sqrt(var_biased + eps)
 struct BNCoef {
     float mean, scale, beta, invstd;
+    float mean_lo;   // mean = mean + mean_lo to ~fp64 accuracy (see bn_center)
 };
 __device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
     const double inv = 1.0 / (double)bn.count;
@@ -31,6 +32,7 @@ __device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
     var = var < 0.0 ? 0.0 : var;
     BNCoef k;
     k.mean = (float)mean;
+    k.mean_lo = (float)(mean - (double)k.mean);
     k.invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
     k.scale = bn.gamma[c] * k.invstd;
     k.beta = bn.beta[c];
@@ -39,6 +41,7 @@ __device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
 // backward constants: dz = k1 * (dy - c1 - xhat * c2), xhat = (z - mean) * invstd
 struct BNBwd {
     float mean, invstd, k1, c1, c2;
+    float mean_lo, c1_lo;
 };
 __device__ __forceinline__ BNBwd bn_bwd_coef(const YunetBN& bn, int C, int c) {
     const BNCoef f = bn_coef(bn, C, c);
@@ -47,9 +50,26 @@ __device__ __forceinline__ BNBwd bn_bwd_coef(const YunetBN& bn, int C, int c) {
     k.mean = f.mean;
     k.invstd = f.invstd;
     k.k1 = f.scale;
-    k.c1 = (float)(bn.bstats[c] * inv);
+    const double c1 = bn.bstats[c] * inv;
+    k.c1 = (float)c1;
+    k.c1_lo = (float)(c1 - (double)k.c1);
     k.c2 = (float)(bn.bstats[C + c] * inv);
+    k.mean_lo = f.mean_lo;
     return k;
+}
+
+// x - mean with the mean carried as a (hi, lo) float pair.  A plain float mean is off by up to
+// 6e-8*|mean| for EVERY element of the channel, which makes sum(xhat) and sum(dz) of the BN
+// backward non-zero by cnt*6e-8*|mean|/sigma; multiplied by mean(p) (depthwise weight gradient)
+// or by the image mean 127 (stem weight gradient) that systematic term reaches 0.3-1 % -- the
+// reference's fp32 path shows the same effect.  One extra subtraction removes it.
+__device__ __forceinline__ float bn_center(float x, float mean_hi, float mean_lo) {
+    return (x - mean_hi) - mean_lo;
+}
+// dz = k1 * (dy - c1 - xhat * c2),  xhat = (z - mean) * invstd, with (hi, lo) mean and c1
+__device__ __forceinline__ float bn_dz(float dy, float z, float mean_hi, float mean_lo, float invstd,
+                                       float k1, float c1_hi, float c1_lo, float c2) {
+    return k1 * (((dy - c1_hi) - c1_lo) - bn_center(z, mean_hi, mean_lo) * invstd * c2);
 }
 
 __device__ __forceinline__ float bnrelu(float x, float mean, float scale, float beta) {

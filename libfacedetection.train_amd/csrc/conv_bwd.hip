@@ -38,7 +38,7 @@ struct BwdGeom {
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
     static constexpr int WORK_F = OFF_PB + IP * LSO;
-    static constexpr int PAR_F = COUT * WS + 9 * COUT + 5 * COUT + 4 * CIN;   // w1 | w2 | out-bn | in-bn
+    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN;   // w1 | w2 | out-bn | in-bn
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
     static constexpr size_t RED2 = (size_t)BWD_THREADS * 8 * 8;       // bstats reduction
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     // the parameter/coefficient block sits after the (possibly larger) reduction work area
     float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);   // [COUT][WS]
     float* s_w2 = s_w1 + COUT * G::WS;                             // [9][COUT]
-    float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2
-    float* s_ci = s_co + 5 * COUT;                                 // mean|scale|beta|invstd
+    float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2|mean_lo|c1_lo
+    float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -83,19 +83,22 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
             s_co[c] = k.mean; s_co[COUT + c] = k.invstd; s_co[2 * COUT + c] = k.k1;
             s_co[3 * COUT + c] = k.c1; s_co[4 * COUT + c] = k.c2;
+            s_co[5 * COUT + c] = k.mean_lo; s_co[6 * COUT + c] = k.c1_lo;
         } else {
             s_co[c] = 0.f; s_co[COUT + c] = 0.f;
             s_co[2 * COUT + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
             s_co[3 * COUT + c] = 0.f; s_co[4 * COUT + c] = 0.f;
+            s_co[5 * COUT + c] = 0.f; s_co[6 * COUT + c] = 0.f;
         }
     }
     for (int c = tid; c < CIN; c += BWD_THREADS) {
         if (bn_in) {
             const BNCoef k = bn_coef(d.in_bn, CIN, c);
             s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
-            s_ci[3 * CIN + c] = k.invstd;
+            s_ci[3 * CIN + c] = k.invstd; s_ci[4 * CIN + c] = k.mean_lo;
         } else {
             s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f; s_ci[3 * CIN + c] = 1.f;
+            s_ci[4 * CIN + c] = 0.f;
         }
     }
     __syncthreads();
@@ -114,10 +117,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) gw2[t] = make_float4(0, 0, 0, 0);
     float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
-    // per-lane fp32 partials of the producer's BN-backward sums, D layout: channel nt*16 + l15
-    float bst[2 * G::NTI];
+    // per-lane partials of the producer's BN-backward sums, D layout: channel nt*16 + l15.
+    // fp64: sum(dy) cancels heavily and feeds c1 = mean(dy) of EVERY dz of the producer --
+    // fp32 partials here showed up as 0.3 % errors in depthwise weight gradients upstream.
+    double bst[2 * G::NTI];
 #pragma unroll
-    for (int i = 0; i < 2 * G::NTI; ++i) bst[i] = 0.0f;
+    for (int i = 0; i < 2 * G::NTI; ++i) bst[i] = 0.0;
     f32x4 gw1[G::TPW];   // dW1: this wave's 16x16 tiles (m = ci block, n = co block)
 #pragma unroll
     for (int i = 0; i < G::TPW; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -173,6 +178,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
             const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
             const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
+            const float4 o_ml = *reinterpret_cast<float4*>(s_co + 5 * COUT + och4 * 4);
+            const float4 o_cl = *reinterpret_cast<float4*>(s_co + 6 * COUT + och4 * 4);
 #pragma unroll
             for (int i = 0; i < G::NDZ; ++i) {
                 const int hp = (tid + BWD_THREADS * i) / G::C4O;
@@ -183,10 +190,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                     if (y >= 0 && y < H && x >= 0 && x < W) {
                         const float4 dy = pdy[i], z = pz[i];
                         if (bn_out) {
-                            v.x = o_k1.x * (dy.x - o_c1.x - (z.x - o_mean.x) * o_inv.x * o_c2.x);
-                            v.y = o_k1.y * (dy.y - o_c1.y - (z.y - o_mean.y) * o_inv.y * o_c2.y);
-                            v.z = o_k1.z * (dy.z - o_c1.z - (z.z - o_mean.z) * o_inv.z * o_c2.z);
-                            v.w = o_k1.w * (dy.w - o_c1.w - (z.w - o_mean.w) * o_inv.w * o_c2.w);
+                            v.x = bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x);
+                            v.y = bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y);
+                            v.z = bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z);
+                            v.w = bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w);
                         } else {
                             v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
                         }
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         for (int nt = 0; nt < G::NTI; ++nt) {
             const int c = nt * 16 + l15;
             const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
+            const float cl = s_ci[4 * CIN + c];
 #pragma unroll
             for (int mi = 0; mi < G::MPW; ++mi)
 #pragma unroll
@@ -318,8 +326,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                         const float xr = *ap;
                         const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
                         v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? v : 0.0f;   // ReLU mask
-                        bst[nt] += v;
-                        bst[G::NTI + nt] = fmaf(v, (xr - cm) * ci, bst[G::NTI + nt]);
+                        bst[nt] += (double)v;
+                        bst[G::NTI + nt] += (double)(v * (bn_center(xr, cm, cl) * ci));
                     }
                     *ap = v;
                 }
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     if (bn_in && d.dx && d.in_bn.bstats) {
         double* red = reinterpret_cast<double*>(smem_raw);  // [BWD_THREADS][2*NTI]
 #pragma unroll
-        for (int i = 0; i < 2 * G::NTI; ++i) red[tid * 2 * G::NTI + i] = (double)bst[i];
+        for (int i = 0; i < 2 * G::NTI; ++i) red[tid * 2 * G::NTI + i] = bst[i];
         __syncthreads();
         if (tid < 2 * CIN) {
             const int which = tid / CIN, c = tid % CIN;
@@ -452,21 +460,22 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float s_all[ALL_F];
     float* s_patch = s_all;
     float* s_dzt = s_all + PATCH_F;
-    __shared__ float s_k[5][16];
+    __shared__ float s_k[7][16];
     const int tid = threadIdx.x;
     const int Ho = H / 2, Wo = W / 2;
     if (tid < 16) {
         const BNBwd k = bn_bwd_coef(bn, 16, tid);
         s_k[0][tid] = k.mean; s_k[1][tid] = k.invstd; s_k[2][tid] = k.k1;
-        s_k[3][tid] = k.c1; s_k[4][tid] = k.c2;
+        s_k[3][tid] = k.c1; s_k[4][tid] = k.c2; s_k[5][tid] = k.mean_lo; s_k[6][tid] = k.c1_lo;
     }
     __syncthreads();
     const int lc4 = tid & 3;  // channel quad in the dz load phase
-    float km[4], ki[4], k1[4], c1[4], c2[4];
+    float km[4], ki[4], k1[4], c1[4], c2[4], kml[4], c1l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         km[i] = s_k[0][lc4 * 4 + i]; ki[i] = s_k[1][lc4 * 4 + i]; k1[i] = s_k[2][lc4 * 4 + i];
         c1[i] = s_k[3][lc4 * 4 + i]; c2[i] = s_k[4][lc4 * 4 + i];
+        kml[i] = s_k[5][lc4 * 4 + i]; c1l[i] = s_k[6][lc4 * 4 + i];
     }
     // role: 4 output-channel quads x 4 tap groups of 7; 16 pixel slices of 16 pixels
     const int role = tid & 15, slice = tid >> 4;
@@ -530,10 +539,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                 const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * 16 + lc4 * 4;
                 const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
                 const float4 z4 = *reinterpret_cast<const float4*>(z + off);
-                v.x = k1[0] * (g4.x - c1[0] - (z4.x - km[0]) * ki[0] * c2[0]);
-                v.y = k1[1] * (g4.y - c1[1] - (z4.y - km[1]) * ki[1] * c2[1]);
-                v.z = k1[2] * (g4.z - c1[2] - (z4.z - km[2]) * ki[2] * c2[2]);
-                v.w = k1[3] * (g4.w - c1[3] - (z4.w - km[3]) * ki[3] * c2[3]);
+                v.x = bn_dz(g4.x, z4.x, km[0], kml[0], ki[0], k1[0], c1[0], c1l[0], c2[0]);
+                v.y = bn_dz(g4.y, z4.y, km[1], kml[1], ki[1], k1[1], c1[1], c1l[1], c2[1]);
+                v.z = bn_dz(g4.z, z4.z, km[2], kml[2], ki[2], k1[2], c1[2], c1l[2], c2[2]);
+                v.w = bn_dz(g4.w, z4.w, km[3], kml[3], ki[3], k1[3], c1[3], c1l[3], c2[3]);
             }
             *reinterpret_cast<float4*>(s_dzt + pix * DZS + lc4 * 4) = v;
         }
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
             for (int j = 0; j < 4; ++j) o[j][i] = (j == am && m > 0.0f) ? gv[i] : 0.0f;
             if (m > 0.0f) {
                 bst[i] += (double)gv[i];
-                bst[4 + i] += (double)(gv[i] * ((zv[am][i] - k[i].mean) * k[i].invstd));
+                bst[4 + i] += (double)(gv[i] * (bn_center(zv[am][i], k[i].mean, k[i].mean_lo) * k[i].invstd));
             }
         }
 #pragma unroll
@@ -692,7 +701,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict_
                 o[i] = on ? gv[i] : 0.0f;
                 if (on) {
                     bsa[i] += (double)gv[i];
-                    bsa[4 + i] += (double)(gv[i] * ((zv[i] - ka[i].mean) * ka[i].invstd));
+                    bsa[4 + i] += (double)(gv[i] * (bn_center(zv[i], ka[i].mean, ka[i].mean_lo) * ka[i].invstd));
                 }
             }
             float4* dst = reinterpret_cast<float4*>(dxa + off);
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict_
             ob[i] = on ? sum[i] : 0.0f;
             if (on) {
                 bsb[i] += (double)sum[i];
-                bsb[4 + i] += (double)(sum[i] * ((zbv[i] - kb[i].mean) * kb[i].invstd));
+                bsb[4 + i] += (double)(sum[i] * (bn_center(zbv[i], kb[i].mean, kb[i].mean_lo) * kb[i].invstd));
             }
         }
         float4* dstb = reinterpret_cast<float4*>(dxb + offb);

@@ -9,6 +9,8 @@
 // output z plus fp64 per-channel sum / sum-of-squares; every consumer applies
 // y = relu((z-mean)*scale+beta) while loading.  Each fused unit therefore reads its input
 // once and writes its output once (SURVEY.md 8d "unit-boundary traffic").
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -176,7 +178,7 @@ struct DpGeom {
     static constexpr int MT = (HP + 15) / 16, MP = MT * 16;
     static constexpr int CM = CIN > COUT ? CIN : COUT;
     static constexpr int LS = CM + 4;           // LDS row stride (floats), 16-byte aligned rows
-    static constexpr int WS = CIN + 2;          // pointwise-weight row stride in LDS
+    static constexpr int WS = CIN + 4;          // pointwise-weight row stride in LDS (16-B rows)
     static constexpr int C4I = CIN / 4, C4O = COUT / 4;
     static constexpr int NT = COUT / 16, KS = CIN / 4;
     static constexpr int PG = 256 / C4O;        // pixel groups in the depthwise phase
@@ -249,7 +251,10 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     };
 
     unsigned long long pc[4] = {0, 0, 0, 0}, c0 = 0;
-    const bool prof = d.prof != nullptr;
+    // prof < 64 is a debug ablation mask (tools/kbench.py --ablate), not a pointer:
+    // 1 skip pointwise MFMA, 2 skip depthwise phase, 4 skip global stores, 8 skip prefetch loads
+    const bool prof = (unsigned long long)d.prof >= 64ull;
+    const unsigned abl = (unsigned long long)d.prof < 64ull ? (unsigned)(unsigned long long)d.prof : 0u;
     int t = blockIdx.x;
     if (t < ntiles) issue(t);
     for (; t < ntiles; t += gridDim.x) {
@@ -281,20 +286,48 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
         __syncthreads();
         if (prof) { const unsigned long long c = clock64(); pc[0] += c - c0; c0 = c; }
         // the registers are free again: fetch the next tile while this one is computed
-        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x);
+        if (t + (int)gridDim.x < ntiles && !(abl & 8)) issue(t + gridDim.x);
         // ---- pw: pointwise 1x1 on the matrix cores, in place ------------------------------------
-        for (int mt = wid; mt < G::MT; mt += 4) {
+        for (int mt = wid; mt < ((abl & 1) ? 0 : G::MT); mt += 4) {
             f32x4 acc[G::NT];
 #pragma unroll
             for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* arow = buf + (mt * 16 + l15) * G::LS + g;
-            const float* brow = s_w1 + l15 * G::WS + g;     // B[k = ci][n = co] = w_pw[co][ci]
+            // MFMA operands are fetched four k-steps at a time with 16-byte LDS reads: k-step
+            // (j, i) of lane group g multiplies input channel 16*j + 4*g + i (any permutation of
+            // the reduction index is valid as long as A and B agree).
+            const float* arow = buf + (mt * 16 + l15) * G::LS + 4 * g;
+            const float* brow = s_w1 + l15 * G::WS + 4 * g;     // B[k = ci][n = co] = w_pw[co][ci]
+            // software pipeline: the operands of k-group j+1 are in flight while the 4*NT MFMAs of
+            // group j issue (hipcc otherwise sinks each LDS read next to its use and every MFMA
+            // quartet eats a full LDS latency)
+            constexpr int NJ = G::KS / 4;
+            float4 a4[NJ];
 #pragma unroll
-            for (int s = 0; s < G::KS; ++s) {
-                const float a = arow[4 * s];
+            for (int j = 0; j < NJ; ++j) a4[j] = *reinterpret_cast<const float4*>(arow + 16 * j);
+            float4 bq[2][G::NT];
 #pragma unroll
-                for (int nt = 0; nt < G::NT; ++nt)
-                    acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
+            for (int nt = 0; nt < G::NT; ++nt)
+                bq[0][nt] = *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) {
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt)
+                        bq[(j + 1) & 1][nt] =
+                            *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS + 16 * (j + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // consecutive MFMAs go to DIFFERENT accumulators (a dependent MFMA costs 44 clk
+                // instead of 32)
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a4[j].x, bq[j & 1][nt].x, acc[nt]);
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a4[j].y, bq[j & 1][nt].y, acc[nt]);
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a4[j].z, bq[j & 1][nt].z, acc[nt]);
+#pragma unroll
+                for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a4[j].w, bq[j & 1][nt].w, acc[nt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
         __syncthreads();
         if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }
         // ---- dw: depthwise 3x3 from LDS, bias, store raw z, BN statistics ------------------------
-        {
+        if (!(abl & 2)) {
             float* zout = d.z + (size_t)n * d.z_img_stride;
             const float* pbase = buf + dtx * G::LS + cq * 4;
             float4 w2[9];
@@ -345,7 +378,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                 }
                 const int y = y0 + r0 + r, x = x0 + dtx;
                 if (y < H && x < W) {
-                    *reinterpret_cast<float4*>(zout + ((size_t)y * W + x) * COUT + cq * 4) = o;
+                    if (!(abl & 4)) *reinterpret_cast<float4*>(zout + ((size_t)y * W + x) * COUT + cq * 4) = o;
                     ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
                     ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
                     ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);

@@ -211,6 +211,7 @@ class Plan:
         self.keep = []          # python objects that must outlive the op arrays
         self.fwd_a, self.fwd_b, self.bwd = [], [], []
         self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
+        self.tensors = {}       # unit name -> (input _T, output _T): introspection / debugging
         f32 = dict(device=dev, dtype=torch.float32)
 
         # ---- BN statistic buffers: one fp64 block, zeroed by a single memset per step
@@ -437,6 +438,7 @@ class Plan:
         u = self.eng.layout.units[name]
         z = self._new_t(x.n, x.h, x.w, u['cout'], bn_name=name + '.bn')
         self._dp_node(x, name, z.buf.data_ptr(), None, z)
+        self.tensors[name] = (x, z)
         return z
 
     def _head(self, x, level, base):

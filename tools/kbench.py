@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--prof', action='store_true')
     ap.add_argument('--ablate', action='store_true')
+    ap.add_argument('--delay', action='store_true', help='forward-kernel phase ablation')
     a = ap.parse_args()
     N = a.n
     cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
@@ -65,6 +66,14 @@ def main():
                       bstats=torch.zeros(2 * co, dtype=torch.float64, device=DEV)) if has_bn else None
         z = torch.empty(N, h, w, co, device=DEV)
         t = timeit(lambda: K.dp_fwd(x, wp, bp, wd, bd, in_bn, out_bn, z=z), a.reps)
+        if a.delay:
+            import ctypes as C
+            import yunet_amd._lib as L
+            dd = K._dp_desc(x, wp, bp, wd, bd, z, in_bn, out_bn)
+            for dl in (0, 1, 2, 4, 8, 3, 15):
+                dd.prof = dl if dl else None
+                tt = timeit(lambda: L.check(L.load().yunet_dp_fwd(C.byref(dd), K._stream()), 'fwd'), a.reps)
+                print(f'   fwd ablate mask {dl:2d}: {tt:.4f} ms')
         if a.prof:
             import ctypes as C
             import yunet_amd._lib as L
