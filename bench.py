@@ -203,11 +203,14 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 '
                          '--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...')
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # 'nccl' is RCCL on ROCm; YUNET_DIST_BACKEND=gloo lets several ranks share one GPU (debug)
+        dist.init_process_group(os.environ.get('YUNET_DIST_BACKEND', 'nccl'), rank=rank,
+                                world_size=world)
 
     import yunet_amd
     import yunet_amd.synthetic as S

@@ -47,10 +47,17 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--prof', action='store_true')
+    ap.add_argument('--calib', action='store_true', help='also run a 256 MiB device copy (PMC unit calibration)')
     ap.add_argument('--ablate', action='store_true')
     ap.add_argument('--delay', action='store_true', help='forward-kernel phase ablation')
     a = ap.parse_args()
     N = a.n
+    if a.calib:
+        src = torch.rand(64 * 1024 * 1024, device=DEV)      # 256 MiB read + 256 MiB written
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
     cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
              ('dp64_40', 64, 64, 40, 40), ('head', 64, 16, 40, 40)]
     for name, ci, co, h, w in cases:

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the evidence a round is judged on (run on the GPU box through gpurun):
+#   1. bench.py JSON line (N=1)                         -> gpurun_out/rNN_bench.json
+#   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv
+#   3. PMC passes (FETCH_SIZE / WRITE_SIZE, separately)  -> gpurun_out/rNN_pmc_{fetch,write}.csv
+#      over tools/kbench.py on the dominant kernels + a calibration copy of known size
+R=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 600 python bench.py --steps 30 --warmup 10 2>/dev/null | tail -1 > $OUT/${R}_bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -o $R -- \
+    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_$R.log 2>&1
+for f in $(find /tmp/prof_$R -name "*kernel_stats.csv"); do cp $f $OUT/${R}_kernel_stats.csv; done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${R}_$c -o p -- \
+      python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 --calib > /tmp/pmc_$c.log 2>&1
+  for f in $(find /tmp/pmc_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_pmc_$c.csv; done
+done
+ls -la $OUT | tail -8
