@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libyunet_hip.so')
+# YUNET_HIP_LIB selects another build of the same library (kernel A/B measurements)
+LIB_PATH = os.environ.get('YUNET_HIP_LIB') or os.path.join(_HERE, 'libyunet_hip.so')
 
 c_f32p = C.c_void_p
 MAX_LEVELS = 5

@@ -21,7 +21,7 @@ template <int CIN, int COUT, int TH, int TW>
 struct BwdGeom {
     static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_;
     static constexpr int IP = TH * TW, IMT = IP / 16;
-    static constexpr int LSO = COUT + 4, LSI = CIN + 4, WS = CIN + 2;
+    static constexpr int LSO = COUT + 4, LSI = CIN + 4, WS = CIN + 4, WST = COUT + 4;
     static constexpr int C4I = CIN / 4, C4O = COUT / 4;
     static constexpr int NTO = COUT / 16, NTI = CIN / 16;
     static constexpr int KSI = CIN / 4, KSO = COUT / 4;
@@ -38,7 +38,7 @@ struct BwdGeom {
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
     static constexpr int WORK_F = OFF_PB + IP * LSO;
-    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN;   // w1 | w2 | out-bn | in-bn
+    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST;   // w1 | w2 | out-bn | in-bn | w1^T
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
     static constexpr size_t RED2 = (size_t)BWD_THREADS * 8 * 8;       // bstats reduction
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     float* s_w2 = s_w1 + COUT * G::WS;                             // [9][COUT]
     float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2|mean_lo|c1_lo
     float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
+    float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -76,7 +77,11 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     // debug ablation mask (tools/kbench.py --ablate): prof < 4096 is a bit mask, not a pointer
     const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
 
-    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
+        const float w = d.w_pw[i];
+        s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
+        s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
+    }
     for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
     for (int c = tid; c < COUT; c += BWD_THREADS) {
         if (bn_out) {
@@ -211,8 +216,6 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = px[i];
         }
         __syncthreads();
-        // prefetch the next tile's global data while this tile is computed
-        if (t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
 
         // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
         if (!(abl & 1)) {
@@ -222,16 +225,33 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                 f32x4 acc[G::NTO];
 #pragma unroll
                 for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* arow = s_a + (mt * 16 + l15) * G::LSI + g;
-                const float* brow = s_w1 + l15 * G::WS + g;
+                // k-permuted operands: within each block of 16 input channels lane group g supplies
+                // channels 4g..4g+3 -- one 16-byte LDS read feeds four MFMA k-steps (A and B use
+                // the same permutation, so the sum over k is unchanged)
+                const float* arow = s_a + (mt * 16 + l15) * G::LSI + 4 * g;
+                const float* brow = s_w1 + l15 * G::WS + 4 * g;
 #pragma unroll
-                for (int s = 0; s < G::KSI; ++s) {
-                    const int c = 4 * s + g;
-                    const float ar = arow[4 * s];
-                    const float a = bn_in ? bnrelu(ar, s_ci[c], s_ci[CIN + c], s_ci[2 * CIN + c]) : ar;
+                for (int q = 0; q < CIN / 16; ++q) {
+                    float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * q);
+                    if (bn_in) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(s_ci + 16 * q + 4 * g);
+                        const float4 s4 = *reinterpret_cast<const float4*>(s_ci + CIN + 16 * q + 4 * g);
+                        const float4 b4 = *reinterpret_cast<const float4*>(s_ci + 2 * CIN + 16 * q + 4 * g);
+                        a4.x = bnrelu(a4.x, m4.x, s4.x, b4.x); a4.y = bnrelu(a4.y, m4.y, s4.y, b4.y);
+                        a4.z = bnrelu(a4.z, m4.z, s4.z, b4.z); a4.w = bnrelu(a4.w, m4.w, s4.w, b4.w);
+                    }
+                    float4 b[G::NTO];
 #pragma unroll
                     for (int nt = 0; nt < G::NTO; ++nt)
-                        acc[nt] = mfma16(a, brow[nt * 16 * G::WS + 4 * s], acc[nt]);
+                        b[nt] = *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS + 16 * q);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.x, b[nt].x, acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.y, b[nt].y, acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.z, b[nt].z, acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.w, b[nt].w, acc[nt]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -274,6 +294,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             *reinterpret_cast<float4*>(pp) = dp;
         }
         __syncthreads();
+        // prefetch the next tile's global data; issued here (not right after the stage) so that the
+        // p GEMM and the VALU phase run without ~64 prefetch registers live -- the two GEMMs, the
+        // mask phase and the store that follow are several microseconds, enough for HBM
+        if (t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
 
         // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
         if (!(abl & 4)) {
@@ -298,14 +322,23 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         if (!(abl & 8)) {
 #pragma unroll
             for (int mi = 0; mi < G::MPW; ++mi) {
-                const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + g;
-                const float* wrow = s_w1 + g * G::WS + l15;
+                const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + 4 * g;
+                const float* wrow = s_w1t + l15 * G::WST + 4 * g;
 #pragma unroll
-                for (int s = 0; s < G::KSO; ++s) {
-                    const float a = prow[4 * s];
+                for (int q = 0; q < COUT / 16; ++q) {     // k = output channels, permuted as above
+                    const float4 a4 = *reinterpret_cast<const float4*>(prow + 16 * q);
+                    float4 b[G::NTI];
 #pragma unroll
                     for (int nt = 0; nt < G::NTI; ++nt)
-                        da[mi][nt] = mfma16(a, wrow[4 * s * G::WS + nt * 16], da[mi][nt]);
+                        b[nt] = *reinterpret_cast<const float4*>(wrow + nt * 16 * G::WST + 16 * q);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.x, b[nt].x, da[mi][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.y, b[nt].y, da[mi][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.z, b[nt].z, da[mi][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.w, b[nt].w, da[mi][nt]);
                 }
             }
         }
