@@ -27,9 +27,12 @@ struct BwdGeom {
     static constexpr int KSI = CIN / 4, KSO = COUT / 4;
     static constexpr int PG = BWD_THREADS / C4O;   // pixel groups of the VALU phase
     static constexpr int PPT = IP / PG;            // pixels (rows) per thread
-    static constexpr int NTILE = NTI * NTO;        // 16x16 tiles of dW1
-    static constexpr int TPW = NTILE >= BWD_WAVES ? NTILE / BWD_WAVES : 1;
-    static constexpr int KSPLIT = NTILE >= BWD_WAVES ? 1 : BWD_WAVES / NTILE;
+    // dW1 (K = pixels): a wave owns MB x NB 16x16 tiles whose rows / columns are interleaved
+    // (ci = MB*m + j, co = NB*n + i), so ONE MB-float and ONE NB-float LDS read feed MB*NB
+    // MFMAs; the NGRP wave groups cover [CIN x COUT], the remaining waves split K
+    static constexpr int MB = (NTI >= 2 && NTI * NTO < 16) ? 2 : 1, NB = NTO >= 2 ? 2 : 1;
+    static constexpr int NGRP = (NTI / MB) * (NTO / NB);
+    static constexpr int KSPLIT = BWD_WAVES / NGRP;
     static constexpr int KSTEPS = (IP / 4) / KSPLIT;  // k-steps of 4 pixels per wave
     static constexpr int NDZ = (HP * C4O + BWD_THREADS - 1) / BWD_THREADS;  // (dy,z) float4 pairs / thread
     static constexpr int NX = (IP * C4I) / BWD_THREADS;                       // x float4 / thread
@@ -38,21 +41,35 @@ struct BwdGeom {
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
     static constexpr int WORK_F = OFF_PB + IP * LSO;
-    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST;   // w1 | w2 | out-bn | in-bn | w1^T
+    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST + 4 * CIN;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
-    static constexpr size_t RED2 = (size_t)BWD_THREADS * 8 * 8;       // bstats reduction
     static constexpr size_t WORK = (size_t)WORK_F * 4;
-    static constexpr size_t WORKB = WORK > RED1 ? (WORK > RED2 ? WORK : RED2) : (RED1 > RED2 ? RED1 : RED2);
+    static constexpr size_t WORKB = WORK > RED1 ? WORK : RED1;
     static constexpr size_t SMEM = WORKB + (size_t)PAR_F * 4;
     static constexpr int MPW = IMT / BWD_WAVES;     // 16-pixel M tiles per wave
+    // only the largest variant is register-bound enough to need opaque() (see below); the small
+    // ones are faster with the per-slot coordinates hoisted out of the tile loop
+    static constexpr bool LAUNDER = CIN * COUT >= 4096;
     static_assert(IP % 16 == 0 && IMT % BWD_WAVES == 0, "whole M tiles per wave");
     static_assert(PG % TW == 0 && IP % PG == 0, "VALU mapping");
     static_assert(BWD_THREADS % C4I == 0 && BWD_THREADS % C4O == 0, "load mapping");
     static_assert((IP * C4I) % BWD_THREADS == 0, "x load mapping");
     static_assert((IP / 4) % KSPLIT == 0, "k split");
-    static_assert(TPW == 1 || NTO % TPW == 0, "a wave's dW1 tiles share the ci block");
+    static_assert(BWD_WAVES % NGRP == 0 && NGRP <= BWD_WAVES, "dW1 wave groups");
 };
+
+// Opaque copy of a thread-invariant value: stops the compiler from hoisting everything derived
+// from it (per-slot offsets, halo coordinates, validity flags) out of the persistent tile loop,
+// where those values would occupy dozens of VGPRs for the whole kernel.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ float tin(float x, float mean, float scale, float beta, float floor_) {
+    return fmaxf(fmaf(x - mean, scale, beta), floor_);
+}
 
 template <int CIN, int COUT, int TH, int TW>
 __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
@@ -68,18 +85,24 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2|mean_lo|c1_lo
     float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
     float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM)
+    double* s_bst = reinterpret_cast<double*>(s_w1t + CIN * G::WST);   // [2][CIN] producer's BN-backward sums
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int H = d.H, W = d.W;
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
     const bool bn_out = d.out_has_bn != 0;
+    // The input transform is applied branch-free where MFMA operands are read: with the identity
+    // coefficients (mean 0, scale 1, beta 0) and a floor of -inf it returns its argument exactly,
+    // so one straight-line GEMM body serves both kinds of unit and can be software-pipelined.
+    const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
     // debug ablation mask (tools/kbench.py --ablate): prof < 4096 is a bit mask, not a pointer
     const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
 
     for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
         const float w = d.w_pw[i];
         s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
+        if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
         s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
     }
     for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
@@ -109,11 +132,6 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     __syncthreads();
 
     // ---- per-thread constants ---------------------------------------------------------------
-    const int och4 = tid % G::C4O;   // output-channel quad in the dz stage
-    const int ich4 = tid % G::C4I;   // input-channel quad in the a stage / dx store
-    float bias_pw[G::NTO];
-#pragma unroll
-    for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = d.b_pw[nt * 16 + l15];
     // VALU phase: channel quad cq, pixel column vtx, rows vr0..vr0+PPT-1
     const int cq = tid % G::C4O, pg = tid / G::C4O;
     const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
@@ -125,15 +143,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     // per-lane partials of the producer's BN-backward sums, D layout: channel nt*16 + l15.
     // fp64: sum(dy) cancels heavily and feeds c1 = mean(dy) of EVERY dz of the producer --
     // fp32 partials here showed up as 0.3 % errors in depthwise weight gradients upstream.
-    double bst[2 * G::NTI];
+    // (kept in LDS, one fp64 atomic per lane / channel block / tile: as registers they cost 16
+    // VGPRs for the whole kernel and pushed the 64-channel variant into scratch)
+    for (int i = tid; i < 2 * CIN; i += BWD_THREADS) s_bst[i] = 0.0;
+    f32x4 gw1[G::MB * G::NB];   // dW1: this wave's interleaved 16x16 tiles
 #pragma unroll
-    for (int i = 0; i < 2 * G::NTI; ++i) bst[i] = 0.0;
-    f32x4 gw1[G::TPW];   // dW1: this wave's 16x16 tiles (m = ci block, n = co block)
-#pragma unroll
-    for (int i = 0; i < G::TPW; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int w1_tile0 = G::KSPLIT == 1 ? wid * G::TPW : wid % G::NTILE;
-    const int w1_kslice = G::KSPLIT == 1 ? 0 : wid / G::NTILE;
-    const int w1_mt = w1_tile0 / G::NTO, w1_nt0 = w1_tile0 % G::NTO;
+    for (int i = 0; i < G::MB * G::NB; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w1_grp = wid % G::NGRP, w1_kslice = wid / G::NGRP;
+    const int w1_ci0 = (w1_grp / (G::NTO / G::NB)) * 16 * G::MB;   // first ci / co of the wave's block
+    const int w1_co0 = (w1_grp % (G::NTO / G::NB)) * 16 * G::NB;
 
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
@@ -142,6 +160,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     // ---- prefetch registers: raw dy / z_out (haloed) and x (interior) of the NEXT tile ------------
     float4 pdy[G::NDZ], pz[G::NDZ], px[G::NX];
     auto issue = [&](int t) {
+        const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
+        const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
         const int n = t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
         const float* zo = d.z + (size_t)n * d.z_img_stride + och4 * 4;
@@ -178,6 +198,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
 
         // ---- stage: dz (BN backward of this unit's own BN) and a = T(x) -> LDS ------------------
         {
+            const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
+            const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
             const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
             const float4 o_inv = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
             const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
@@ -206,14 +228,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                     *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
                 }
             }
-        }
-        // the interior input tile goes to LDS RAW; the input transform (BN+ReLU of the producer)
-        // is applied where MFMA operands are read, so the raw values stay available for the
-        // ReLU mask and the BN-backward sums of the producer
+            // the interior input tile goes to LDS RAW; the input transform (BN+ReLU of the
+            // producer) is applied where MFMA operands are read, so the raw values stay available
+            // for the ReLU mask and the BN-backward sums of the producer
 #pragma unroll
-        for (int i = 0; i < G::NX; ++i) {
-            const int ip = (tid + BWD_THREADS * i) / G::C4I;
-            *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = px[i];
+            for (int i = 0; i < G::NX; ++i) {
+                const int ip = (tid + BWD_THREADS * i) / G::C4I;
+                *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = px[i];
+            }
         }
         __syncthreads();
 
@@ -230,29 +252,49 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                 // the same permutation, so the sum over k is unchanged)
                 const float* arow = s_a + (mt * 16 + l15) * G::LSI + 4 * g;
                 const float* brow = s_w1 + l15 * G::WS + 4 * g;
+                const float* crow = s_ci + 4 * g;
+                // rolled loop, operands of block q+1 loaded while block q is on the matrix cores
+                // (a rolled loop bounds the live operand set to two blocks -- a fully unrolled one
+                // lets the scheduler hoist every read and spill)
+                constexpr int NQ = CIN / 16, UNR = (NQ > 2 && G::NTO >= 4) ? 1 : NQ;
+                float4 a_c = *reinterpret_cast<const float4*>(arow);
+                float4 m_c = *reinterpret_cast<const float4*>(crow);
+                float4 s_c = *reinterpret_cast<const float4*>(crow + CIN);
+                float4 t_c = *reinterpret_cast<const float4*>(crow + 2 * CIN);
+                float4 b_c[G::NTO];
 #pragma unroll
-                for (int q = 0; q < CIN / 16; ++q) {
-                    float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * q);
-                    if (bn_in) {
-                        const float4 m4 = *reinterpret_cast<const float4*>(s_ci + 16 * q + 4 * g);
-                        const float4 s4 = *reinterpret_cast<const float4*>(s_ci + CIN + 16 * q + 4 * g);
-                        const float4 b4 = *reinterpret_cast<const float4*>(s_ci + 2 * CIN + 16 * q + 4 * g);
-                        a4.x = bnrelu(a4.x, m4.x, s4.x, b4.x); a4.y = bnrelu(a4.y, m4.y, s4.y, b4.y);
-                        a4.z = bnrelu(a4.z, m4.z, s4.z, b4.z); a4.w = bnrelu(a4.w, m4.w, s4.w, b4.w);
-                    }
-                    float4 b[G::NTO];
+                for (int nt = 0; nt < G::NTO; ++nt)
+                    b_c[nt] = *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS);
+#pragma unroll UNR
+                for (int q = 0; q < NQ; ++q) {
+                    const int qn = UNR == 1 ? 16 * ((q + 1) % NQ) : (q + 1 < NQ ? 16 * (q + 1) : 0);
+                    const float4 a_n = *reinterpret_cast<const float4*>(arow + qn);
+                    const float4 m_n = *reinterpret_cast<const float4*>(crow + qn);
+                    const float4 s_n = *reinterpret_cast<const float4*>(crow + CIN + qn);
+                    const float4 t_n = *reinterpret_cast<const float4*>(crow + 2 * CIN + qn);
+                    float4 b_n[G::NTO];
 #pragma unroll
                     for (int nt = 0; nt < G::NTO; ++nt)
-                        b[nt] = *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS + 16 * q);
+                        b_n[nt] = *reinterpret_cast<const float4*>(brow + nt * 16 * G::WS + qn);
+                    const float ax = tin(a_c.x, m_c.x, s_c.x, t_c.x, relu_floor);
+                    const float ay = tin(a_c.y, m_c.y, s_c.y, t_c.y, relu_floor);
+                    const float az = tin(a_c.z, m_c.z, s_c.z, t_c.z, relu_floor);
+                    const float aw = tin(a_c.w, m_c.w, s_c.w, t_c.w, relu_floor);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.x, b[nt].x, acc[nt]);
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(ax, b_c[nt].x, acc[nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.y, b[nt].y, acc[nt]);
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(ay, b_c[nt].y, acc[nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.z, b[nt].z, acc[nt]);
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(az, b_c[nt].z, acc[nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(a4.w, b[nt].w, acc[nt]);
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = mfma16(aw, b_c[nt].w, acc[nt]);
+                    a_c = a_n; m_c = m_n; s_c = s_n; t_c = t_n;
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) b_c[nt] = b_n[nt];
                 }
+                float bias_pw[G::NTO];
+#pragma unroll
+                for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = s_w1[(nt * 16 + l15) * G::WS + CIN];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ip = mt * 16 + 4 * g + r;
@@ -301,17 +343,36 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
 
         // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
         if (!(abl & 4)) {
-            const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + w1_mt * 16 + l15;
-            const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + w1_nt0 * 16 + l15;
-            const int ca = w1_mt * 16 + l15;
-            const float am = s_ci[ca], as_ = s_ci[CIN + ca], ab = s_ci[2 * CIN + ca];
+            const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + w1_ci0 + G::MB * l15;
+            const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + w1_co0 + G::NB * l15;
+            float am[G::MB], as_[G::MB], ab[G::MB];
+#pragma unroll
+            for (int j = 0; j < G::MB; ++j) {
+                const int ca = w1_ci0 + G::MB * l15 + j;
+                am[j] = s_ci[ca]; as_[j] = s_ci[CIN + ca]; ab[j] = s_ci[2 * CIN + ca];
+            }
 #pragma unroll 8
             for (int s = 0; s < G::KSTEPS; ++s) {
-                const float ar = ap[4 * s * G::LSI];
-                const float av = bn_in ? bnrelu(ar, am, as_, ab) : ar;
+                float av[G::MB], bv[G::NB];
+                if (G::MB == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(ap + 4 * s * G::LSI);
+                    av[0] = t2.x; av[G::MB - 1] = t2.y;
+                } else {
+                    av[0] = ap[4 * s * G::LSI];
+                }
+                if (G::NB == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(bp + 4 * s * G::LSO);
+                    bv[0] = t2.x; bv[G::NB - 1] = t2.y;
+                } else {
+                    bv[0] = bp[4 * s * G::LSO];
+                }
 #pragma unroll
-                for (int i = 0; i < G::TPW; ++i)
-                    gw1[i] = mfma16(av, bp[4 * s * G::LSO + i * 16], gw1[i]);
+                for (int j = 0; j < G::MB; ++j) {
+                    const float a = tin(av[j], am[j], as_[j], ab[j], relu_floor);
+#pragma unroll
+                    for (int i = 0; i < G::NB; ++i)
+                        gw1[j * G::NB + i] = mfma16(a, bv[i], gw1[j * G::NB + i]);
+                }
             }
         }
         f32x4 da[G::MPW][G::NTI];
@@ -324,64 +385,95 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             for (int mi = 0; mi < G::MPW; ++mi) {
                 const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + 4 * g;
                 const float* wrow = s_w1t + l15 * G::WST + 4 * g;
+                constexpr int NQ = COUT / 16, UNR = (NQ > 2 && G::NTI >= 4) ? 1 : NQ;   // k = output channels, permuted as above
+                float4 a_c = *reinterpret_cast<const float4*>(prow);
+                float4 b_c[G::NTI];
 #pragma unroll
-                for (int q = 0; q < COUT / 16; ++q) {     // k = output channels, permuted as above
-                    const float4 a4 = *reinterpret_cast<const float4*>(prow + 16 * q);
-                    float4 b[G::NTI];
+                for (int nt = 0; nt < G::NTI; ++nt)
+                    b_c[nt] = *reinterpret_cast<const float4*>(wrow + nt * 16 * G::WST);
+#pragma unroll UNR
+                for (int q = 0; q < NQ; ++q) {
+                    const int qn = UNR == 1 ? 16 * ((q + 1) % NQ) : (q + 1 < NQ ? 16 * (q + 1) : 0);
+                    const float4 a_n = *reinterpret_cast<const float4*>(prow + qn);
+                    float4 b_n[G::NTI];
 #pragma unroll
                     for (int nt = 0; nt < G::NTI; ++nt)
-                        b[nt] = *reinterpret_cast<const float4*>(wrow + nt * 16 * G::WST + 16 * q);
+                        b_n[nt] = *reinterpret_cast<const float4*>(wrow + nt * 16 * G::WST + qn);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.x, b[nt].x, da[mi][nt]);
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a_c.x, b_c[nt].x, da[mi][nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.y, b[nt].y, da[mi][nt]);
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a_c.y, b_c[nt].y, da[mi][nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.z, b[nt].z, da[mi][nt]);
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a_c.z, b_c[nt].z, da[mi][nt]);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a4.w, b[nt].w, da[mi][nt]);
+                    for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = mfma16(a_c.w, b_c[nt].w, da[mi][nt]);
+                    a_c = a_n;
+#pragma unroll
+                    for (int nt = 0; nt < G::NTI; ++nt) b_c[nt] = b_n[nt];
                 }
             }
         }
         __syncthreads();  // every wave is done reading s_a for dW1
+        if (bn_in) {
 #pragma unroll
-        for (int nt = 0; nt < G::NTI; ++nt) {
-            const int c = nt * 16 + l15;
-            const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
-            const float cl = s_ci[4 * CIN + c];
+            for (int nt = 0; nt < G::NTI; ++nt) {
+                const int c = nt * 16 + l15;
+                const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
+                const float cl = s_ci[4 * CIN + c];
+                double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-            for (int mi = 0; mi < G::MPW; ++mi)
+                for (int mi = 0; mi < G::MPW; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ip = (wid * G::MPW + mi) * 16 + 4 * g + r;
-                    float* ap = s_a + ip * G::LSI + c;
-                    float v = da[mi][nt][r];
-                    if (bn_in) {
+                    for (int r = 0; r < 4; ++r) {
+                        const int ip = (wid * G::MPW + mi) * 16 + 4 * g + r;
+                        float* ap = s_a + ip * G::LSI + c;
                         const float xr = *ap;
                         const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
-                        v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? v : 0.0f;   // ReLU mask
-                        bst[nt] += (double)v;
-                        bst[G::NTI + nt] += (double)(v * (bn_center(xr, cm, cl) * ci));
+                        const float v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? da[mi][nt][r] : 0.0f;   // ReLU mask
+                        t0 += (double)v;
+                        t1 += (double)(v * (bn_center(xr, cm, cl) * ci));
+                        *ap = v;
                     }
-                    *ap = v;
-                }
+                __hip_atomic_fetch_add(s_bst + c, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s_bst + CIN + c, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < G::NTI; ++nt)
+#pragma unroll
+                for (int mi = 0; mi < G::MPW; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_a[((wid * G::MPW + mi) * 16 + 4 * g + r) * G::LSI + nt * 16 + l15] = da[mi][nt][r];
         }
         __syncthreads();
 
         // ---- dx store (coalesced) + BN-backward sums of the producer ------------------------------
         if (d.dx && !(abl & 16)) {
+            const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
+            const int ich4 = tid % G::C4I;
             float* dxo = d.dx + (size_t)n * d.x_img_stride + ich4 * 4;
+            float4 old[G::NX];
+            if (d.accumulate_dx) {      // all read-modify-write loads in flight before the first add
+#pragma unroll
+                for (int i = 0; i < G::NX; ++i) {
+                    const int ip = (tid + BWD_THREADS * i) / G::C4I;
+                    const int y = y0 + ip / TW, x = x0 + ip % TW;
+                    old[i] = make_float4(0, 0, 0, 0);
+                    if (y < H && x < W)
+                        old[i] = *reinterpret_cast<const float4*>(dxo + ((size_t)y * W + x) * CIN);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < G::NX; ++i) {
                 const int ip = (tid + BWD_THREADS * i) / G::C4I;
                 const int y = y0 + ip / TW, x = x0 + ip % TW;
                 if (y < H && x < W) {
                     float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
-                    float4* dst = reinterpret_cast<float4*>(dxo + ((size_t)y * W + x) * CIN);
                     if (d.accumulate_dx) {
-                        const float4 o = *dst;
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        v.x += old[i].x; v.y += old[i].y; v.z += old[i].z; v.w += old[i].w;
                     }
-                    *dst = v;
+                    *reinterpret_cast<float4*>(dxo + ((size_t)y * W + x) * CIN) = v;
                 }
             }
         }
@@ -397,12 +489,13 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     for (int ks = 0; ks < G::KSPLIT; ++ks) {
         if (w1_kslice == ks) {
 #pragma unroll
-            for (int i = 0; i < G::TPW; ++i) {
-                const int nt = w1_nt0 + i;
+            for (int j = 0; j < G::MB; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s_gw1[(nt * 16 + l15) * CIN + w1_mt * 16 + 4 * g + r] += gw1[i][r];
-            }
+                for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_gw1[(w1_co0 + G::NB * l15 + i) * CIN + w1_ci0 + G::MB * (4 * g + r) + j] +=
+                            gw1[j * G::NB + i][r];
         }
         __syncthreads();
     }
@@ -439,21 +532,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             __syncthreads();
         }
     }
-    // (c) BN-backward sums of the producer: fp64 block reduce, one atomic per channel
-    if (bn_in && d.dx && d.in_bn.bstats) {
-        double* red = reinterpret_cast<double*>(smem_raw);  // [BWD_THREADS][2*NTI]
-#pragma unroll
-        for (int i = 0; i < 2 * G::NTI; ++i) red[tid * 2 * G::NTI + i] = bst[i];
-        __syncthreads();
-        if (tid < 2 * CIN) {
-            const int which = tid / CIN, c = tid % CIN;
-            const int nt = c >> 4, lc = c & 15;
-            double v = 0.0;
-            for (int p = 0; p < BWD_THREADS / 16; ++p)      // all (wave, g) pairs holding channel c
-                v += red[(p * 16 + lc) * 2 * G::NTI + which * G::NTI + nt];
-            atomic_add_f64(d.in_bn.bstats + which * CIN + c, v);
-        }
-    }
+    // (c) BN-backward sums of the producer: one global fp64 atomic per channel
+    if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
 }
 
 template <int CIN, int COUT, int TH, int TW>
