@@ -11,6 +11,7 @@
 #define CONV_BLOCKS 1024
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // D = A(16x4) * B(4x16) + C, exact fp32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];

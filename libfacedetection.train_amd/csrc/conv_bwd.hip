@@ -158,35 +158,52 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     const int ntiles = d.N * tiles_img;
 
     // ---- prefetch registers: raw dy / z_out (haloed) and x (interior) of the NEXT tile ------------
+    // Loaded through per-image buffer descriptors: one 32-bit byte offset per slot, and a slot
+    // outside the image (zero padding of the halo, ragged last tiles) simply gets an offset past
+    // the end -- the hardware range check returns 0, so there are no branches and no 64-bit
+    // address arithmetic.  okmask keeps one validity bit per halo slot for the stage.
     float4 pdy[G::NDZ], pz[G::NDZ], px[G::NX];
+    unsigned okmask = 0;
+    const unsigned zbytes = (unsigned)(H * W * COUT) * 4u, xbytes = (unsigned)(H * W * CIN) * 4u;
+    constexpr int PSTEP = BWD_THREADS / G::C4O;            // halo pixels between a thread's slots
+    constexpr int HSTEP_Y = PSTEP / G::HW_, HSTEP_X = PSTEP % G::HW_;
     auto issue = [&](int t) {
         const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
         const int n = t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const float* zo = d.z + (size_t)n * d.z_img_stride + och4 * 4;
-        const float* dyo = d.dy + (size_t)n * d.z_img_stride + och4 * 4;
-        const float* xin = d.x + (size_t)n * d.x_img_stride + ich4 * 4;
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.dy) + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.z) + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        int hp = tid / G::C4O;
+        int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < G::NDZ; ++i) {
-            const int hp = (tid + BWD_THREADS * i) / G::C4O;
-            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            pdy[i] = make_float4(0, 0, 0, 0);
+            const bool ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((y * W + x) * COUT + och4 * 4) * 4u : zbytes;
+            okmask |= ok ? (1u << i) : 0u;
+            const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, off, 0, 0);
+            pdy[i] = *reinterpret_cast<const float4*>(&vdy);
             pz[i] = make_float4(0, 0, 0, 0);
-            if (hp < G::HP && y >= 0 && y < H && x >= 0 && x < W) {
-                const size_t off = ((size_t)y * W + x) * COUT;
-                pdy[i] = *reinterpret_cast<const float4*>(dyo + off);
-                if (bn_out) pz[i] = *reinterpret_cast<const float4*>(zo + off);
+            if (bn_out) {
+                const u32x4 vz = __builtin_amdgcn_raw_buffer_load_b128(r_z, off, 0, 0);
+                pz[i] = *reinterpret_cast<const float4*>(&vz);
             }
+            hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
+            if (hx >= G::HW_) { hx -= G::HW_; ++hy; }
         }
 #pragma unroll
         for (int i = 0; i < G::NX; ++i) {
             const int ip = (tid + BWD_THREADS * i) / G::C4I;
             const int y = y0 + ip / TW, x = x0 + ip % TW;
-            px[i] = make_float4(0, 0, 0, 0);
-            if (y < H && x < W)
-                px[i] = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN);
+            const unsigned off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
+            px[i] = *reinterpret_cast<const float4*>(&vx);
         }
     };
 
@@ -207,23 +224,23 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
             const float4 o_ml = *reinterpret_cast<float4*>(s_co + 5 * COUT + och4 * 4);
             const float4 o_cl = *reinterpret_cast<float4*>(s_co + 6 * COUT + och4 * 4);
+            const int hp0 = tid / G::C4O;
 #pragma unroll
             for (int i = 0; i < G::NDZ; ++i) {
-                const int hp = (tid + BWD_THREADS * i) / G::C4O;
-                if (hp < G::HP) {
-                    const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
-                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                    float4 v = make_float4(0, 0, 0, 0);
-                    if (y >= 0 && y < H && x >= 0 && x < W) {
-                        const float4 dy = pdy[i], z = pz[i];
-                        if (bn_out) {
-                            v.x = bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x);
-                            v.y = bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y);
-                            v.z = bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z);
-                            v.w = bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w);
-                        } else {
-                            v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
-                        }
+                const int hp = hp0 + PSTEP * i;
+                if ((i + 1) * PSTEP <= G::HP || hp < G::HP) {
+                    const float4 dy = pdy[i], z = pz[i];
+                    float4 v;
+                    if (bn_out) {
+                        // zero padding of dz: a slot outside the image loaded dy = z = 0, which the
+                        // BN backward would turn into a non-zero value
+                        const bool ok = (okmask >> i) & 1u;
+                        v.x = ok ? bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x) : 0.0f;
+                        v.y = ok ? bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y) : 0.0f;
+                        v.z = ok ? bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z) : 0.0f;
+                        v.w = ok ? bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w) : 0.0f;
+                    } else {
+                        v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
                     }
                     *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
                 }
@@ -452,29 +469,25 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         if (d.dx && !(abl & 16)) {
             const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
             const int ich4 = tid % G::C4I;
-            float* dxo = d.dx + (size_t)n * d.x_img_stride + ich4 * 4;
-            float4 old[G::NX];
-            if (d.accumulate_dx) {      // all read-modify-write loads in flight before the first add
-#pragma unroll
-                for (int i = 0; i < G::NX; ++i) {
-                    const int ip = (tid + BWD_THREADS * i) / G::C4I;
-                    const int y = y0 + ip / TW, x = x0 + ip % TW;
-                    old[i] = make_float4(0, 0, 0, 0);
-                    if (y < H && x < W)
-                        old[i] = *reinterpret_cast<const float4*>(dxo + ((size_t)y * W + x) * CIN);
-                }
-            }
+            const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(d.dx + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+            unsigned off[G::NX];
+            u32x4 old[G::NX];
 #pragma unroll
             for (int i = 0; i < G::NX; ++i) {
                 const int ip = (tid + BWD_THREADS * i) / G::C4I;
                 const int y = y0 + ip / TW, x = x0 + ip % TW;
-                if (y < H && x < W) {
-                    float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
-                    if (d.accumulate_dx) {
-                        v.x += old[i].x; v.y += old[i].y; v.z += old[i].z; v.w += old[i].w;
-                    }
-                    *reinterpret_cast<float4*>(dxo + ((size_t)y * W + x) * CIN) = v;
+                off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+                if (d.accumulate_dx) old[i] = __builtin_amdgcn_raw_buffer_load_b128(r_dx, off[i], 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < G::NX; ++i) {
+                const int ip = (tid + BWD_THREADS * i) / G::C4I;
+                float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
+                if (d.accumulate_dx) {
+                    const float4 o = *reinterpret_cast<const float4*>(&old[i]);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
             }
         }
         __syncthreads();

@@ -109,7 +109,7 @@ def main():
         lib = L.load()
         t = timeit(lambda: L.check(lib.yunet_dp_bwd(C.byref(d), K._stream()), 'bwd'), a.reps)
         if a.ablate:
-            for m in (1, 2, 4, 8, 16, 32, 63):
+            for m in (1, 2, 4, 8, 16, 32, 63, 62, 61, 59, 55, 47, 31):
                 d.prof = m
                 tt = timeit(lambda: L.check(lib.yunet_dp_bwd(C.byref(d), K._stream()), 'bwd'), a.reps)
                 print(f'   ablate mask {m:2d}: {tt:.4f} ms (full {t:.4f})')
