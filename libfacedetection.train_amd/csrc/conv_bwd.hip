@@ -48,9 +48,8 @@ struct BwdGeom {
     static constexpr size_t WORKB = WORK > RED1 ? WORK : RED1;
     static constexpr size_t SMEM = WORKB + (size_t)PAR_F * 4;
     static constexpr int MPW = IMT / BWD_WAVES;     // 16-pixel M tiles per wave
-    // only the largest variant is register-bound enough to need opaque() (see below); the small
-    // ones are faster with the per-slot coordinates hoisted out of the tile loop
-    static constexpr bool LAUNDER = CIN * COUT >= 4096;
+    // the register-bound variants re-derive thread-invariant indices per tile (see opaque())
+    static constexpr bool LAUNDER = COUT >= 64 || CIN * COUT >= 2048 || TH * TW > 128;
     static_assert(IP % 16 == 0 && IMT % BWD_WAVES == 0, "whole M tiles per wave");
     static_assert(PG % TW == 0 && IP % PG == 0, "VALU mapping");
     static_assert(BWD_THREADS % C4I == 0 && BWD_THREADS % C4O == 0, "load mapping");
@@ -60,8 +59,8 @@ struct BwdGeom {
 };
 
 // Opaque copy of a thread-invariant value: stops the compiler from hoisting everything derived
-// from it (per-slot offsets, halo coordinates, validity flags) out of the persistent tile loop,
-// where those values would occupy dozens of VGPRs for the whole kernel.
+// from it (per-slot offsets, halo coordinates) out of the persistent tile loop, where those
+// values would occupy dozens of VGPRs for the whole kernel.
 __device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                 }
                 float bias_pw[G::NTO];
 #pragma unroll
-                for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = s_w1[(nt * 16 + l15) * G::WS + CIN];
+                for (int nt = 0; nt < G::NTO; ++nt) bias_pw[nt] = s_w1[(nt * 16 + (G::LAUNDER ? opaque(l15) : l15)) * G::WS + CIN];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ip = mt * 16 + 4 * g + r;
@@ -325,32 +324,50 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         __syncthreads();
 
         // ---- depthwise backward on the VALU; dp overwrites p in place ----------------------------
-#pragma unroll 1
-        for (int r = 0; r < ((abl & 2) ? 0 : G::PPT); ++r) {
-            const int ty = vr0 + r;
-            const bool in = (y0 + ty) < H && (x0 + vtx) < W;
-            float* pp = s_pb + (ty * TW + vtx) * G::LSO + cq * 4;
-            const float4 p = *reinterpret_cast<const float4*>(pp);
-            float4 dp = make_float4(0, 0, 0, 0);
+        // A thread owns a channel quad and a column of PPT rows.  The dz column triple is walked
+        // once with a sliding window: each dz value is read from LDS one time and feeds every
+        // output row it touches (3x fewer LDS reads than tap-by-tap when PPT = 4).
+        if (!(abl & 2)) {
+            float4 pv[G::PPT], dp[G::PPT];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int r = 0; r < G::PPT; ++r) {
+                pv[r] = *reinterpret_cast<const float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4);
+                dp[r] = make_float4(0, 0, 0, 0);
+            }
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
+            for (int b = 0; b < 3; ++b) {
+                float4 wk[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    wk[a] = *reinterpret_cast<const float4*>(s_w2 + (8 - (3 * a + b)) * COUT + cq * 4);
+#pragma unroll
+                for (int j = 0; j < G::PPT + 2; ++j) {
                     const float4 z4 = *reinterpret_cast<const float4*>(
-                        s_dz + ((ty + a) * G::HW_ + vtx + b) * G::LSO + cq * 4);
-                    const int k = 8 - (3 * a + b);
-                    const float4 wk = *reinterpret_cast<const float4*>(s_w2 + k * COUT + cq * 4);
-                    dp.x = fmaf(z4.x, wk.x, dp.x); dp.y = fmaf(z4.y, wk.y, dp.y);
-                    dp.z = fmaf(z4.z, wk.z, dp.z); dp.w = fmaf(z4.w, wk.w, dp.w);
-                    gw2[k].x = fmaf(p.x, z4.x, gw2[k].x); gw2[k].y = fmaf(p.y, z4.y, gw2[k].y);
-                    gw2[k].z = fmaf(p.z, z4.z, gw2[k].z); gw2[k].w = fmaf(p.w, z4.w, gw2[k].w);
-                    if (a == 1 && b == 1) {
-                        gb2.x += z4.x; gb2.y += z4.y; gb2.z += z4.z; gb2.w += z4.w;
+                        s_dz + ((vr0 + j) * G::HW_ + vtx + b) * G::LSO + cq * 4);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const int r = j - a;
+                        if (r < 0 || r >= G::PPT) continue;
+                        const int k = 8 - (3 * a + b);
+                        dp[r].x = fmaf(z4.x, wk[a].x, dp[r].x); dp[r].y = fmaf(z4.y, wk[a].y, dp[r].y);
+                        dp[r].z = fmaf(z4.z, wk[a].z, dp[r].z); dp[r].w = fmaf(z4.w, wk[a].w, dp[r].w);
+                        gw2[k].x = fmaf(pv[r].x, z4.x, gw2[k].x); gw2[k].y = fmaf(pv[r].y, z4.y, gw2[k].y);
+                        gw2[k].z = fmaf(pv[r].z, z4.z, gw2[k].z); gw2[k].w = fmaf(pv[r].w, z4.w, gw2[k].w);
+                        if (a == 1 && b == 1) {
+                            gb2.x += z4.x; gb2.y += z4.y; gb2.z += z4.z; gb2.w += z4.w;
+                        }
                     }
                 }
-            if (!in) dp = make_float4(0, 0, 0, 0);
-            gb1.x += dp.x; gb1.y += dp.y; gb1.z += dp.z; gb1.w += dp.w;
-            *reinterpret_cast<float4*>(pp) = dp;
+                // one column at a time: without this the scheduler hoists all 3*(PPT+2) reads
+                if (G::PPT > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < G::PPT; ++r) {
+                const bool in = (y0 + vr0 + r) < H && (x0 + vtx) < W;
+                if (!in) dp[r] = make_float4(0, 0, 0, 0);
+                gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
+                *reinterpret_cast<float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4) = dp[r];
+            }
         }
         __syncthreads();
         // prefetch the next tile's global data; issued here (not right after the stage) so that the
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             float am[G::MB], as_[G::MB], ab[G::MB];
 #pragma unroll
             for (int j = 0; j < G::MB; ++j) {
-                const int ca = w1_ci0 + G::MB * l15 + j;
+                const int ca = w1_ci0 + G::MB * (G::LAUNDER ? opaque(l15) : l15) + j;
                 am[j] = s_ci[ca]; as_[j] = s_ci[CIN + ca]; ab[j] = s_ci[2 * CIN + ca];
             }
 #pragma unroll 8
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         if (bn_in) {
 #pragma unroll
             for (int nt = 0; nt < G::NTI; ++nt) {
-                const int c = nt * 16 + l15;
+                const int c = nt * 16 + (G::LAUNDER ? opaque(l15) : l15);   // (keeps the 5*NTI coefficients out of loop-invariant registers)
                 const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
                 const float cl = s_ci[4 * CIN + c];
                 double t0 = 0.0, t1 = 0.0;
