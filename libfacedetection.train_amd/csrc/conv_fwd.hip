@@ -233,22 +233,34 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     const int tiles_img = tiles_x * tiles_y;
     const int ntiles = d.N * tiles_img;
 
-    // prefetch registers: this thread's slice of the NEXT tile's raw halo input
+    // prefetch registers: this thread's slice of the NEXT tile's raw halo input, loaded through
+    // a per-image buffer descriptor: one 32-bit byte offset per slot, and a slot outside the
+    // image gets an offset past the end (the hardware range check returns 0) -- no branches, no
+    // 64-bit address arithmetic
     float4 pre[G::NLD];
+    const unsigned xbytes = (unsigned)(H * W * CIN) * 4u, zbytes = (unsigned)(H * W * COUT) * 4u;
+    constexpr int PSTEP = 256 / G::C4I;                   // halo pixels between a thread's slots
+    constexpr int HSTEP_Y = PSTEP / G::HW_, HSTEP_X = PSTEP % G::HW_;
     auto issue = [&](int t) {
         const int n = t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const float* xin = d.x + (size_t)n * d.x_img_stride + lch4 * 4;
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        int hp = tid / G::C4I;
+        int hy = hp / G::HW_, hx = hp - hy * G::HW_;
 #pragma unroll
         for (int i = 0; i < G::NLD; ++i) {
-            const int hp = (tid + 256 * i) / G::C4I;
-            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            pre[i] = make_float4(0, 0, 0, 0);
-            if (hp < G::HP && y >= 0 && y < H && x >= 0 && x < W)
-                pre[i] = *reinterpret_cast<const float4*>(xin + ((size_t)y * W + x) * CIN);
+            const bool ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((y * W + x) * CIN + lch4 * 4) * 4u : xbytes;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
+            pre[i] = *reinterpret_cast<const float4*>(&v);
+            hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
+            if (hx >= G::HW_) { hx -= G::HW_; ++hy; }
         }
     };
+    // identity units run the same straight-line transform: (x - 0) * 1 + 0 floored at -inf
+    const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
 
     unsigned long long pc[4] = {0, 0, 0, 0}, c0 = 0;
     // prof < 64 is a debug ablation mask (tools/kbench.py --ablate), not a pointer:
@@ -266,19 +278,18 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
             const float4 cm = *reinterpret_cast<const float4*>(s_coef + lch4 * 4);
             const float4 cs = *reinterpret_cast<const float4*>(s_coef + CIN + lch4 * 4);
             const float4 cb = *reinterpret_cast<const float4*>(s_coef + 2 * CIN + lch4 * 4);
+            const int hp0 = tid / G::C4I;
 #pragma unroll
             for (int i = 0; i < G::NLD; ++i) {
-                const int hp = (tid + 256 * i) / G::C4I;
-                if (hp < G::MP) {
-                    const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
-                    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const int hp = hp0 + PSTEP * i;
+                if ((i + 1) * PSTEP <= G::MP || hp < G::MP) {
+                    // (halo pixels outside the image hold T(0) here; their pointwise output is
+                    // forced to zero in the pw epilogue, which is what the depthwise pads with)
                     float4 v = pre[i];
-                    if (bn_in && hp < G::HP && y >= 0 && y < H && x >= 0 && x < W) {
-                        v.x = bnrelu(v.x, cm.x, cs.x, cb.x);
-                        v.y = bnrelu(v.y, cm.y, cs.y, cb.y);
-                        v.z = bnrelu(v.z, cm.z, cs.z, cb.z);
-                        v.w = bnrelu(v.w, cm.w, cs.w, cb.w);
-                    }
+                    v.x = fmaxf(fmaf(v.x - cm.x, cs.x, cb.x), relu_floor);
+                    v.y = fmaxf(fmaf(v.y - cm.y, cs.y, cb.y), relu_floor);
+                    v.z = fmaxf(fmaf(v.z - cm.z, cs.z, cb.z), relu_floor);
+                    v.w = fmaxf(fmaf(v.w - cm.w, cs.w, cb.w), relu_floor);
                     *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
                 }
             }
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
         if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }
         // ---- dw: depthwise 3x3 from LDS, bias, store raw z, BN statistics ------------------------
         if (!(abl & 2)) {
-            float* zout = d.z + (size_t)n * d.z_img_stride;
+            const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
             const float* pbase = buf + dtx * G::LS + cq * 4;
             float4 w2[9];
 #pragma unroll
@@ -378,7 +389,9 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                 }
                 const int y = y0 + r0 + r, x = x0 + dtx;
                 if (y < H && x < W) {
-                    if (!(abl & 4)) *reinterpret_cast<float4*>(zout + ((size_t)y * W + x) * COUT + cq * 4) = o;
+                    if (!(abl & 4))
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z,
+                                                               (unsigned)((y * W + x) * COUT + cq * 4) * 4u, 0, 0);
                     ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
                     ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
                     ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
