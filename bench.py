@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 KIND, H, W, BATCH = 'n', 320, 320, 256
 
 
@@ -77,6 +78,36 @@ def op_bytes(op, L):
     return 0
 
 
+def op_flops(op, L):
+    """Algorithmic matrix FLOPs of one launch: the 1x1 pointwise GEMM of a ConvDPUnit is
+    2*cin*cout per pixel forward, and two such GEMMs (weight and input gradient) backward.
+    (The backward kernel also recomputes the forward GEMM; that is not counted here.)"""
+    if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
+        d = op.dp
+        f = 2 * d.N * d.H * d.W * d.cin * d.cout
+        return f if op.opcode == L.OP_DP_FWD else 2 * f
+    return 0
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/rNN_pmc_traffic.json, written by tools/profile_round.sh + tools/pmc_summary.py:
+    separate FETCH_SIZE / WRITE_SIZE passes over this same bench step)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                          'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    try:
+        tab = json.load(open(files[-1]))['kernels']
+        key = kernel.replace(' ', '')
+        if key in tab:
+            return tab[key]['traffic_bytes'], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def op_name(op, L):
     names = {L.OP_STEM_FWD: 'stem_fwd_kernel', L.OP_STEM_BWD: 'stem_bwd_kernel',
              L.OP_POOL_FWD: 'pool_fwd_kernel', L.OP_POOL_BWD: 'pool_bwd_kernel',
@@ -116,14 +147,16 @@ def profile_ops(eng, reps=3):
                 continue            # warm-up pass
             for k, e0, e1 in evs:
                 op = arr[k]
-                a = agg.setdefault(op_name(op, L), dict(launches=0, ms=0.0, bytes=0))
+                a = agg.setdefault(op_name(op, L), dict(launches=0, ms=0.0, bytes=0, flops=0))
                 a['launches'] += 1
                 a['ms'] += e0.elapsed_time(e1)
                 a['bytes'] += op_bytes(op, L)
+                a['flops'] += op_flops(op, L)
     for a in agg.values():
         a['launches'] //= reps
         a['ms'] /= reps
         a['bytes'] //= reps
+        a['flops'] //= reps
     return agg
 
 
@@ -277,9 +310,16 @@ def main():
         name, top = max(agg.items(), key=lambda kv: kv[1]['ms'])
         per_launch_ms = top['ms'] / top['launches']
         achieved = top['bytes'] / top['launches'] / (per_launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(name)
+        tflops = top['flops'] / top['launches'] / (per_launch_ms * 1e-3) / 1e12
         res['roofline'] = {
             'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'kernel': name,
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'kernel': name,
+            # the same kernel against the exact-fp32 matrix-core ceiling (v_mfma_f32_16x16x4_f32:
+            # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz); algorithmic GEMM FLOPs only
+            'mfma': {'achieved': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4)},
             'launches_per_step': top['launches'], 'avg_launch_ms': round(per_launch_ms, 4),
             'algorithmic_bytes_per_launch': top['bytes'] // top['launches'],
             'share_of_step': round(top['ms'] / tot, 3),

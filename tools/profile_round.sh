@@ -13,9 +13,16 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -o $R -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_$R.log 2>&1
 for f in $(find /tmp/prof_$R -name "*kernel_stats.csv"); do cp $f $OUT/${R}_kernel_stats.csv; done
+#      3a. over the bench step itself (per-launch means of every kernel of the step)
+#      3b. over tools/kbench.py --calib (a 256 MiB device copy of known size: counter calibration)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${R}_$c -o p -- \
-      python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 --calib > /tmp/pmc_$c.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
   for f in $(find /tmp/pmc_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_pmc_$c.csv; done
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcc_${R}_$c -o p -- \
+      python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 --calib > /tmp/pmcc_$c.log 2>&1
+  for f in $(find /tmp/pmcc_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_pmc_calib_$c.csv; done
 done
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_FETCH_SIZE.csv $OUT/${R}_pmc_WRITE_SIZE.csv $OUT/${R}_pmc_traffic.json
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_calib_FETCH_SIZE.csv $OUT/${R}_pmc_calib_WRITE_SIZE.csv $OUT/${R}_pmc_calib.json
 ls -la $OUT | tail -8
