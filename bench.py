@@ -115,7 +115,8 @@ def op_name(op, L):
              L.OP_ASSIGN: 'assign_kernel', L.OP_LOSS: 'loss_kernel',
              L.OP_LOSS_NORM: 'loss_norm_kernel', L.OP_LOSS_FINALIZE: 'loss_finalize_kernel',
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
-             L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset'}
+             L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',
+             L.OP_REDUCE_BATCH: 'reduce_partials_batch_kernel', L.OP_BN_BATCH: 'bn_batch_kernel'}
     if op.opcode == L.OP_DP_FWD:
         return f'dp_fwd_kernel<{op.dp.cin},{op.dp.cout},8,16>'
     if op.opcode == L.OP_DP_BWD:

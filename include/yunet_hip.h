@@ -131,6 +131,17 @@ int yunet_bn_batch(const int32_t* table, int n, const double* stats_base, float*
 int yunet_reduce_partials(const float* partials, int blocks, int width, float* out,
                           int accumulate, void* stream);
 
+/* The same reduction for a whole table of partial buffers in ONE launch (all weight-gradient
+ * reductions of a backward pass: ~20 tiny kernels otherwise).  `jobs` is a DEVICE array;
+ * chunk0 = index of the job's first 64-column chunk in the grid (running sum of
+ * ceil(width / 64)), total_chunks = the grid size. */
+typedef struct YunetReduceJob {
+    const float* partials;   /* [blocks, width] */
+    float* out;              /* [width] */
+    int32_t blocks, width, accumulate, chunk0;
+} YunetReduceJob;
+int yunet_reduce_partials_batch(const YunetReduceJob* jobs, int njobs, int total_chunks, void* stream);
+
 /* ---- loss step (mmdet/models/dense_heads/yunet_head.py:418-604) ---------------------- */
 
 #define YUNET_MAX_LEVELS 5
@@ -205,7 +216,7 @@ enum {
     YUNET_OP_POOL_FWD, YUNET_OP_POOL_BWD, YUNET_OP_UPADD_FWD, YUNET_OP_UPADD_BWD,
     YUNET_OP_BN_RUNNING, YUNET_OP_BN_PARAM_GRAD, YUNET_OP_REDUCE_PARTIALS,
     YUNET_OP_ASSIGN, YUNET_OP_LOSS_NORM, YUNET_OP_LOSS, YUNET_OP_LOSS_FINALIZE,
-    YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH
+    YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH, YUNET_OP_REDUCE_BATCH
 };
 typedef struct YunetOp {
     int32_t opcode;

@@ -17,7 +17,7 @@ T_IDENTITY, T_BNRELU = 0, 1
 BOX_EIOU, BOX_DIOU = 0, 1
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
- OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH) = range(1, 19)
+ OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH) = range(1, 20)
 
 
 class YunetBN(C.Structure):
@@ -79,6 +79,7 @@ _SIGNATURES = {
     'yunet_bn_param_grad': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]),
     'yunet_bn_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_void_p, C.c_int, C.c_void_p]),
+    'yunet_reduce_partials_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'yunet_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p]),
     'yunet_assign': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +

@@ -118,6 +118,9 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
                 rc = yunet_reduce_partials((const float*)o.p[0], o.i[0], o.i[1], (float*)o.p[1],
                                            o.i[2], stream);
                 break;
+            case YUNET_OP_REDUCE_BATCH:
+                rc = yunet_reduce_partials_batch((const YunetReduceJob*)o.p[0], o.i[0], o.i[1], stream);
+                break;
             case YUNET_OP_ASSIGN:
                 rc = yunet_assign((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                   (const int32_t*)o.p[3], (const int32_t*)o.p[4], &o.lv, o.i[0], o.i[1],

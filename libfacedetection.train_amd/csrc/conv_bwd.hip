@@ -924,6 +924,28 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
 }
 
+// table-driven variant: workgroup -> (job, 64-column chunk); same arithmetic and order as above
+__global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const YunetReduceJob* __restrict__ jobs,
+                                                                     int njobs) {
+    __shared__ float s[16][64];
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].chunk0 <= (int)blockIdx.x) ++j;
+    const YunetReduceJob job = jobs[j];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = ((int)blockIdx.x - job.chunk0) * 64 + lane;
+    float v = 0.0f;
+    if (col < job.width)
+        for (int b = sl; b < job.blocks; b += 16) v += job.partials[(size_t)b * job.width + col];
+    s[sl][lane] = v;
+    __syncthreads();
+    if (sl == 0 && col < job.width) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s[k][lane];
+        job.out[col] = job.accumulate ? job.out[col] + t : t;
+    }
+}
+
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -1011,5 +1033,13 @@ extern "C" int yunet_reduce_partials(const float* partials, int blocks, int widt
     if (blocks < 1 || width < 1) return YUNET_EINVAL;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64), dim3(1024), 0,
                        (hipStream_t)stream, partials, blocks, width, out, accumulate);
+    return hip_status();
+}
+
+extern "C" int yunet_reduce_partials_batch(const YunetReduceJob* jobs, int njobs, int total_chunks,
+                                           void* stream) {
+    if (!jobs || njobs < 1 || total_chunks < njobs) return YUNET_EINVAL;
+    hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(total_chunks), dim3(1024), 0,
+                       (hipStream_t)stream, jobs, njobs);
     return hip_status();
 }

@@ -17,6 +17,7 @@ PyTorch supplies device memory, streams and torch.distributed only.
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -329,8 +330,13 @@ class Plan:
             i=[len(rows_f), 0], f=[BN_MOMENTUM]))
 
         # ---- backward: reverse of the forward nodes
+        self.reduce_jobs = []   # (partials ptr, grad ptr, rows, width, accumulate) of every unit
         for node in reversed(self.bwd_nodes):
             node()
+        # all weight-gradient partial reductions in ONE launch (table lives on the device)
+        self.reduce_table, chunk = K.reduce_job_table(self.reduce_jobs, dev)
+        self.bwd.append(self._op(L.OP_REDUCE_BATCH, p=[self.reduce_table.data_ptr()],
+                                 i=[len(self.reduce_jobs), chunk]))
         self.bwd.append(self._op(
             L.OP_BN_BATCH, p=[self.bn_table_b.data_ptr(), self.stats.data_ptr(), None, None,
                               fp.grad.data_ptr()], i=[len(rows_b), 1], f=[0.0]))
@@ -411,8 +417,7 @@ class Plan:
             op.bn[0] = self._bn_struct('backbone.model0.bn1', cnt)
             self.bwd.append(op)
             self.img_ptr_ops.append(('bwd', len(self.bwd) - 1))
-            self.bwd.append(self._op(L.OP_REDUCE_PARTIALS, p=[part.data_ptr(), gptr],
-                                     i=[blocks, width, 0]))
+            self.reduce_jobs.append((part.data_ptr(), gptr, blocks, width, 0))
         self.bwd_nodes.append(bwd)
 
     def _dp_desc(self, x, name, z, z_img_stride=None):
@@ -473,8 +478,7 @@ class Plan:
             op = self._op(L.OP_DP_BWD)
             op.dp = d2
             self.bwd.append(op)
-            self.bwd.append(self._op(L.OP_REDUCE_PARTIALS, p=[part.data_ptr(), gptr],
-                                     i=[blocks, width, 0]))
+            self.reduce_jobs.append((part.data_ptr(), gptr, blocks, width, 0))
         self.bwd_nodes.append(bwd)
 
     def _pool(self, x):

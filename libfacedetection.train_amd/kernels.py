@@ -89,6 +89,31 @@ def reduce_partials(part, out, accumulate=False):
                                            int(accumulate), _stream()), 'yunet_reduce_partials')
 
 
+def reduce_job_table(jobs, device):
+    """Device table of YunetReduceJob records for yunet_reduce_partials_batch.
+    jobs: (partials ptr, out ptr, rows, width, accumulate).  Returns (table, total_chunks)."""
+    import numpy as np
+    tab = np.zeros((len(jobs), 4), dtype=np.int64)          # 32-byte records
+    chunk = 0
+    for r, (pp, op, rows, width, acc) in enumerate(jobs):
+        tab[r, 0], tab[r, 1] = pp, op
+        tab[r, 2] = (int(width) << 32) | int(rows)          # int32 blocks | int32 width
+        tab[r, 3] = (chunk << 32) | int(acc)                # int32 accumulate | int32 chunk0
+        chunk += (width + 63) // 64
+    return torch.from_numpy(tab).to(device), chunk
+
+
+def reduce_partials_batch(parts, outs, accumulate=None):
+    """out_k[j] (+)= sum_b parts_k[b, j] for every pair, one launch."""
+    acc = accumulate or [False] * len(parts)
+    jobs = [(p.data_ptr(), o.data_ptr(), p.shape[0], p.shape[1], int(a))
+            for p, o, a in zip(parts, outs, acc)]
+    tab, chunks = reduce_job_table(jobs, parts[0].device)
+    L.check(L.load().yunet_reduce_partials_batch(_p(tab), len(jobs), chunks, _stream()),
+            'yunet_reduce_partials_batch')
+    return tab      # keep alive until the launch has run
+
+
 def _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, x_img_stride=None,
              z_img_stride=None):
     n, h, w, cin = x.shape

@@ -91,7 +91,14 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
         plan = eng.get_plan(2, h, h, 3)
         assert plan.P == sum((h // s) ** 2 for s in (8, 16, 32))
         ops = plan.fwd_a + plan.fwd_b + plan.bwd
-        assert all(1 <= op.opcode <= 18 for op in ops)
+        assert all(1 <= op.opcode <= L.OP_REDUCE_BATCH for op in ops)
+        # every unit's weight-gradient partials are reduced by the one batched op at the end
+        red = [op for op in plan.bwd if op.opcode == L.OP_REDUCE_BATCH]
+        assert len(red) == 1 and red[0].i[0] == len(plan.reduce_jobs)
+        assert red[0].i[1] == sum((w + 63) // 64 for _, _, _, w, _ in plan.reduce_jobs)
+        tab = plan.reduce_table.numpy()
+        assert [int(r[2] & 0xffffffff) for r in tab] == [j[2] for j in plan.reduce_jobs]     # rows
+        assert [int(r[2] >> 32) for r in tab] == [j[3] for j in plan.reduce_jobs]            # width
         n_dp = sum(1 for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
         assert n_dp == len(E.ParamLayout.dp_units(eng.arch)) + 3
         assert sum(1 for op in plan.bwd if op.opcode == L.OP_DP_BWD) == n_dp

@@ -283,6 +283,26 @@ def test_sgd_matches_torch():
     assert rel_err(p, ref.detach()) < 1e-6
 
 
+def test_reduce_partials_batch():
+    """One launch over a table of partial buffers == the per-buffer reductions, bit for bit
+    (same summation order), incl. ragged widths and the accumulate flag."""
+    k = K()
+    g = torch.Generator().manual_seed(2)
+    shapes = [(256, 4816), (768, 448), (37, 1), (256, 1360), (5, 64), (256, 65)]
+    parts = [torch.randn(r, w, generator=g).to(DEV) for r, w in shapes]
+    base = [torch.randn(w, generator=g).to(DEV) for _, w in shapes]
+    acc = [False, True, False, True, True, False]
+    want = [b.clone() for b in base]
+    for p, o, a in zip(parts, want, acc):
+        k.reduce_partials(p, o, accumulate=a)
+    got = [b.clone() for b in base]
+    tab = k.reduce_partials_batch(parts, got, acc)
+    torch.cuda.synchronize()
+    for w_, g_ in zip(want, got):
+        assert torch.equal(w_, g_)
+    del tab
+
+
 def test_reduce_partials():
     k = K()
     g = torch.Generator().manual_seed(1)
