@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     constexpr int NLD = (3 * PH * PW4 + 255) / 256;     // float4 loads per thread per tile
     __shared__ float s_patch[3 * PH * PWS];
     __shared__ __attribute__((aligned(16))) float s_w[27][16];
-    __shared__ double s_red[4][32];
+    __shared__ double s_stat[32];      // sum | sum of squares per channel, fp64
     const int tid = threadIdx.x;
     const int Ho = H / 2, Wo = W / 2;
     for (int i = tid; i < 27 * 16; i += 256) {
@@ -45,48 +45,60 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     float bias[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) bias[c] = b[c];
-    double ssum[16], ssq[16];
+    // BN statistics: fp32 per thread over at most STAT_FLUSH tiles (2*STAT_FLUSH values), then a
+    // wave reduction and one fp64 LDS atomic per channel -- 32 fp64 accumulators per thread
+    // would cost 64 VGPRs and a wave of occupancy
+    constexpr int STAT_FLUSH = 8;
+    float ts[16], tq[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) ssum[c] = ssq[c] = 0.0;
+    for (int c = 0; c < 16; ++c) ts[c] = tq[c] = 0.0f;
+    int since_flush = 0;
+    if (tid < 32) s_stat[tid] = 0.0;
 
     const int tiles_x = (Wo + STEM_TW - 1) / STEM_TW, tiles_y = (Ho + STEM_TH - 1) / STEM_TH;
     const int ntiles = N * tiles_x * tiles_y;
     const int cg = tid & 15, ty = tid >> 4;     // column group (STEM_PX pixels), row
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // register prefetch of the NEXT tile's patch (aligned float4 slots of the planar image)
+    // through a per-image buffer descriptor: slots above / below / beside the image get an
+    // out-of-range offset and read as zero (W is a multiple of 4, so a slot is never cut)
+    float4 ld[NLD];
+    const unsigned img_bytes = (unsigned)(3 * H * W) * 4u;
+    auto issue = [&](int t) {
+        const int n = t / (tiles_x * tiles_y);
+        const int r = t - n * tiles_x * tiles_y;
+        const int y0 = (r / tiles_x) * STEM_TH, x0 = (r % tiles_x) * STEM_TW;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img) + (size_t)n * 3 * H * W, 0,
+                                                          img_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int rowi = i / PW4, c4 = i - rowi * PW4;
+            const int ci = rowi / PH, py = rowi - ci * PH;
+            const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 4 + 4 * c4;
+            const bool ok = rowi < 3 * PH && (unsigned)iy < (unsigned)H && ix >= 0 && ix + 3 < W;
+            const unsigned off = ok ? (unsigned)((ci * H + iy) * W + ix) * 4u : img_bytes;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            ld[k] = *reinterpret_cast<const float4*>(&v);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
         const int n = t / (tiles_x * tiles_y);
         const int r = t - n * tiles_x * tiles_y;
         const int y0 = (r / tiles_x) * STEM_TH, x0 = (r % tiles_x) * STEM_TW;
         __syncthreads();
-        {
-            float4 ld[NLD];
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = tid + 256 * k;
-                const int rowi = i / PW4, c4 = i - rowi * PW4;
-                const int ci = rowi / PH, py = rowi - ci * PH;
-                const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 4 + 4 * c4;
-                ld[k] = make_float4(0, 0, 0, 0);
-                if (rowi < 3 * PH && iy >= 0 && iy < H && ix >= 0 && ix + 3 < W)
-                    ld[k] = *reinterpret_cast<const float4*>(img + (((size_t)n * 3 + ci) * H + iy) * W + ix);
-                else if (rowi < 3 * PH && iy >= 0 && iy < H) {      // row edge: element-wise
-                    const float* src = img + (((size_t)n * 3 + ci) * H + iy) * W;
-                    if (ix + 0 >= 0 && ix + 0 < W) ld[k].x = src[ix + 0];
-                    if (ix + 1 >= 0 && ix + 1 < W) ld[k].y = src[ix + 1];
-                    if (ix + 2 >= 0 && ix + 2 < W) ld[k].z = src[ix + 2];
-                    if (ix + 3 >= 0 && ix + 3 < W) ld[k].w = src[ix + 3];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = tid + 256 * k;
-                const int rowi = i / PW4, c4 = i - rowi * PW4;
-                if (rowi < 3 * PH) {
-                    float* dst = s_patch + rowi * PWS + 4 * c4;
-                    dst[0] = ld[k].x; dst[1] = ld[k].y; dst[2] = ld[k].z; dst[3] = ld[k].w;
-                }
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int rowi = i / PW4, c4 = i - rowi * PW4;
+            if (rowi < 3 * PH) {
+                float* dst = s_patch + rowi * PWS + 4 * c4;
+                dst[0] = ld[k].x; dst[1] = ld[k].y; dst[2] = ld[k].z; dst[3] = ld[k].w;
             }
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x);
         float acc[STEM_PX][16];
 #pragma unroll
         for (int p = 0; p < STEM_PX; ++p)
@@ -118,9 +130,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                 }
             }
         const int oy = y0 + ty;
-        float ts[16], tq[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) ts[c] = tq[c] = 0.0f;
 #pragma unroll
         for (int p = 0; p < STEM_PX; ++p) {
             const int ox = x0 + STEM_PX * cg + p;
@@ -137,31 +146,26 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                 }
             }
         }
+        if (++since_flush == STAT_FLUSH || t + (int)gridDim.x >= ntiles) {
+            since_flush = 0;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            ssum[c] += (double)ts[c];
-            ssq[c] += (double)tq[c];
-        }
-    }
-    // block reduction of the statistics: wave shuffles, then 4 waves through LDS
+            for (int c = 0; c < 16; ++c) {
+                float a = ts[c], q = tq[c];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        double a = ssum[c], q = ssq[c];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            a += __shfl_xor(a, o, 64);
-            q += __shfl_xor(q, o, 64);
-        }
-        if ((tid & 63) == 0) {
-            s_red[tid >> 6][c] = a;
-            s_red[tid >> 6][16 + c] = q;
+                for (int o = 32; o >= 1; o >>= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if ((tid & 63) == 0) {
+                    __hip_atomic_fetch_add(&s_stat[c], (double)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_stat[16 + c], (double)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ts[c] = tq[c] = 0.0f;
+            }
         }
     }
     __syncthreads();
-    if (tid < 32) {
-        const double v = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
-        atomic_add_f64(&stats[tid], v);
-    }
+    if (tid < 32) atomic_add_f64(&stats[tid], s_stat[tid]);
 }
 
 // --------------------------------------------------------------------------- ConvDPUnit
@@ -538,7 +542,8 @@ extern "C" int yunet_stem_fwd(const float* img, const float* w, const float* b, 
                               double* stats, int N, int H, int W, int cmid, void* stream) {
     if (cmid != 16 || (H & 1) || (W & 1)) return YUNET_EINVAL;
     const int tiles = N * ((W / 2 + STEM_TW - 1) / STEM_TW) * ((H / 2 + STEM_TH - 1) / STEM_TH);
-    const int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    // persistent grid = resident workgroups (158 VGPRs -> 3 waves/SIMD -> 3 per CU on 256 CUs)
+    const int grid = tiles < 768 ? tiles : 768;
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, w, b, z,
                        stats, N, H, W);
     return hip_status();
