@@ -243,8 +243,9 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # 'nccl' is RCCL on ROCm; YUNET_DIST_BACKEND=gloo lets several ranks share one GPU (debug)
-        dist.init_process_group(os.environ.get('YUNET_DIST_BACKEND', 'nccl'), rank=rank,
-                                world_size=world)
+        backend = os.environ.get('YUNET_DIST_BACKEND', 'nccl')
+        kw = dict(device_id=dev) if backend == 'nccl' else {}     # bind the communicator to this GPU
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     import yunet_amd
     import yunet_amd.synthetic as S
@@ -273,15 +274,16 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    bar = dict(device_ids=[local]) if world > 1 and dist.get_backend() == 'nccl' else {}
     if world > 1:
-        dist.barrier()
+        dist.barrier(**bar)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         out = step(i)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(**bar)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -335,7 +337,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
-        dist.barrier()
+        dist.barrier(**bar)
         dist.destroy_process_group()
 
 

@@ -328,3 +328,50 @@ if __name__ == '__main__':
     print('params', sum(p.numel() for p in m.parameters()))
     m.load_state_dict(load_checkpoint_state('yunet_n.pth'), strict=True)
     print('ckpt loaded strict')
+
+
+# --------------------------------------------------------------------------- data pipeline
+def load_pipeline_transforms(imresize=None, imflip=None):
+    """Import the UNMODIFIED reference `mmdet/datasets/pipelines/transforms.py` (RandomSquareCrop,
+    Resize, RandomFlip, Normalize) for pinning `oracle/pipeline_oracle.py`.
+
+    Its module-level imports need cv2 (absent here) and mmcv image ops; both are stubbed:
+    `mmcv.imresize` / `mmcv.imflip` are supplied by the caller (the geometry, RNG call order and
+    box / keypoint arithmetic all run in the reference's own code; only the pixel interpolation of
+    cv2.resize is outside what can be executed here).  `np.int`, removed from numpy >= 1.24 and
+    used at transforms.py:1073, is restored as an alias of `int`.
+    """
+    import numpy as np
+    load_reference()
+    if not hasattr(np, 'int'):
+        np.int = int
+    if 'cv2' not in sys.modules:
+        sys.modules['cv2'] = types.ModuleType('cv2')
+    mmcv = sys.modules['mmcv']
+    mmcv.is_list_of = lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)
+    mmcv.is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(x, t) for x in seq)
+    if imresize is not None:
+        mmcv.imresize = imresize
+    if imflip is not None:
+        mmcv.imflip = imflip
+    mmcv.imnormalize = lambda img, mean, std, to_rgb=True: ((img - mean) / std).astype(np.float32)
+    for name in ('mmdet.datasets', 'mmdet.datasets.pipelines', 'mmdet.core.evaluation'):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = [os.path.join(REF_ROOT, *name.split('.'))]
+            mod.__package__ = name
+            sys.modules[name] = mod
+            parent, child = name.rsplit('.', 1)
+            setattr(sys.modules[parent], child, mod)
+    if 'mmdet.datasets.builder' not in sys.modules:
+        b = types.ModuleType('mmdet.datasets.builder')
+        b.PIPELINES = _Registry('pipeline')
+        sys.modules['mmdet.datasets.builder'] = b
+        sys.modules['mmdet.datasets'].builder = b
+    core = sys.modules['mmdet.core']
+    ms = sys.modules['mmdet.core.mask.structures']
+    core.BitmapMasks, core.PolygonMasks = ms.BitmapMasks, ms.PolygonMasks
+    core.find_inside_bboxes = None
+    sys.modules['mmdet.utils'].log_img_scale = lambda *a, **k: False
+    importlib.import_module('mmdet.core.evaluation.bbox_overlaps')
+    return importlib.import_module('mmdet.datasets.pipelines.transforms')

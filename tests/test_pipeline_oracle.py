@@ -1,0 +1,101 @@
+"""not-gpu: the input-pipeline oracle (oracle/pipeline_oracle.py) against fixtures produced by
+the UNMODIFIED reference transforms (oracle/make_golden_pipeline.py): crop window, kept boxes,
+box / keypoint arithmetic and flip are pinned bit for bit; image pixels are checked too, but the
+reference run used the oracle's own bilinear (cv2 is absent), so for the Resize interpolation
+this is a consistency check only."""
+import os
+
+import numpy as np
+import pytest
+
+import pipeline_oracle as P
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLD, name))
+    seed, it, S, n = int(g['seed']), int(g['iteration']), int(g['S']), int(g['n'])
+    rng = np.random.default_rng(seed)
+    srcs = []
+    for i in range(n):
+        h, w, total = [int(v) for v in g[f'src_shape_{i}']]
+        img, boxes, kps = P.synth_image(rng, h, w, int(g[f'src_g_{i}']))
+        assert int(img.astype(np.int64).sum()) == total, 'synthetic source drifted from the fixture'
+        assert np.array_equal(boxes, g[f'src_boxes_{i}']) and np.array_equal(kps, g[f'src_kps_{i}'])
+        srcs.append((img, boxes, kps))
+    return g, seed, it, S, srcs
+
+
+@pytest.mark.parametrize('name', ['pipeline_s160.npz', 'pipeline_s320.npz'])
+def test_pipeline_oracle_matches_reference(name):
+    g, seed, it, S, srcs = load_case(name)
+    retries = 0
+    for i, (img, boxes, kps) in enumerate(srcs):
+        r = P.augment_image(img, boxes, kps, seed, it, i, S, g['crop_choice'])
+        cw, flip, draws, kept = [int(v) for v in g[f'meta_{i}']]
+        assert (int(r['params'][2]), int(r['params'][3])) == (cw, flip)
+        assert int(r['mask'].sum()) == kept
+        assert np.array_equal(r['boxes'], g[f'boxes_{i}']), f'boxes differ (image {i})'
+        assert np.array_equal(r['kps'], g[f'kps_{i}']), f'keypoints differ (image {i})'
+        im = r['img']
+        assert np.array_equal(im[:, :16, :16], g[f'img_corner_{i}'])
+        assert np.array_equal(im[:, S // 2 - 8:S // 2 + 8, S // 2 - 8:S // 2 + 8], g[f'img_center_{i}'])
+        dig = np.stack([im.astype(np.float64).sum((1, 2)), (im.astype(np.float64) ** 2).sum((1, 2))])
+        assert np.array_equal(dig, g[f'img_digest_{i}'])
+        retries += draws > 4
+    if 's160' in name:
+        assert retries >= 2, 'the fixture should exercise the crop retry loop'
+
+
+def test_generator_known_answers_and_ranges():
+    """The counter-based generator is plain 32-bit integer arithmetic: fixed known answers (the
+    same constants are asserted against the device in the gpu tests) and range properties."""
+    assert P.mix32(0) == 0 and P.mix32(1) == 0x688990C0
+    key = P.stream_key(7, 0, 3)
+    assert key == 0x1AB37C03
+    assert [P.rand_u32(key, c) for c in range(3)] == [0x5C3935CA, 0xD1A61929, 0x3BA1B0E2]
+    st = P.Stream(7, 0, 3)
+    vals = [st.next_u32() for _ in range(4)]
+    assert len(set(vals)) == 4 and all(0 <= v < 2 ** 32 for v in vals)
+    st = P.Stream(123, 9, 0)
+    r = [st.randint(-5, 7) for _ in range(2000)]
+    assert min(r) == -5 and max(r) == 6
+    c = [st.choice_index(6) for _ in range(3000)]
+    assert sorted(set(c)) == [0, 1, 2, 3, 4, 5]
+    counts = np.bincount(c)
+    assert counts.min() > 400                      # roughly uniform
+    u = np.array([st.uniform() for _ in range(4000)])
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.03
+
+
+def test_resize_linear_properties():
+    """Restated cv2 INTER_LINEAR: identity at equal size, constants preserved, exact 2x
+    down-sampling averages 2x2 blocks, edge clamp."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 255, (37, 37, 3)).astype(np.float32)
+    assert np.array_equal(P.resize_linear(a, 37), a)
+    assert np.array_equal(P.resize_linear(np.full((50, 50, 3), 7.0, np.float32), 23),
+                          np.full((23, 23, 3), 7.0, np.float32))
+    b = rng.integers(0, 256, (64, 64, 1)).astype(np.float32)
+    want = (b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2]) / 4
+    assert np.allclose(P.resize_linear(b, 32), want, atol=1e-4)
+    up = P.resize_linear(b, 128)
+    assert up[0, 0, 0] == b[0, 0, 0] and up[-1, -1, 0] == b[-1, -1, 0]
+
+
+def test_crop_window_outside_the_image_pads_with_128():
+    img = np.full((10, 20, 3), 9, np.uint8)
+    out = P.crop_image(img.astype(np.float32), -5, -10, 30)
+    assert out.shape == (30, 30, 3)
+    assert (out[10:20, 5:25] == 9).all()
+    out[10:20, 5:25] = 128
+    assert (out == 128).all()
+
+
+def test_collate_pads_and_truncates():
+    res = [dict(boxes=np.ones((3, 4), np.float32), kps=np.ones((3, 5, 3), np.float32)),
+           dict(boxes=np.ones((70, 4), np.float32), kps=np.ones((70, 5, 3), np.float32))]
+    gb, gk, cnt = P.collate(res, 64)
+    assert cnt.tolist() == [3, 64] and gb.shape == (2, 64, 4) and gk.shape == (2, 64, 5, 3)
+    assert gb[0, 3:].sum() == 0 and gb[1].sum() == 64 * 4
