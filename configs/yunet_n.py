@@ -18,6 +18,21 @@ workflow = [('train', 1)]
 data = dict(samples_per_gpu=256, workers_per_gpu=0,
             train=dict(type='SyntheticWiderFace', img_scale=(320, 320), iters_per_epoch=403))
 
+# The reference's train pipeline (configs/yunet_n.py:36-56 there), executed on the GPU by
+# yunet_amd.pipelines.DevicePipeline.  To train through it from decoded uint8 sources:
+#   --cfg-options data.train.type=SyntheticSourceImages
+train_pipeline = [
+    dict(type='LoadImageFromFile', to_float32=True),
+    dict(type='LoadAnnotations', with_bbox=True, with_keypoints=True),
+    dict(type='RandomSquareCrop', crop_choice=[0.5, 0.7, 0.9, 1.1, 1.3, 1.5]),
+    dict(type='Resize', img_scale=(320, 320), keep_ratio=False),
+    dict(type='RandomFlip', flip_ratio=0.5),
+    dict(type='Normalize', mean=[0., 0., 0.], std=[1., 1., 1.], to_rgb=False),
+    dict(type='DefaultFormatBundle'),
+    dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels', 'gt_bboxes_ignore', 'gt_keypointss']),
+]
+data['train']['pipeline'] = train_pipeline
+
 _stages_n = [[3, 16, 16], [16, 64], [64, 64], [64, 64], [64, 64], [64, 64]]
 model = dict(
     type='YuNet',

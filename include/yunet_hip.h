@@ -230,6 +230,39 @@ typedef struct YunetOp {
 } YunetOp;
 int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
 
+/* ---- device input pipeline ----------------------------------------
+ * The reference's TRAIN pipeline (configs/yunet_n.py:36-56) on the device:
+ *   RandomSquareCrop  mmdet/datasets/pipelines/transforms.py:975-1169
+ *   Resize(keep_ratio=False)          transforms.py:242-299 (mmcv.imresize -> cv2 INTER_LINEAR)
+ *   RandomFlip + 5-landmark swap      transforms.py:425-546
+ *   collate to padded GT              mmdet/datasets/pipelines/formatting.py:206-249
+ * Random draws come from a counter-based 32-bit generator keyed by (seed, iteration, image) --
+ * restated in oracle/pipeline_oracle.py and pinned against the unmodified reference classes. */
+typedef struct YunetAugCfg {
+    int32_t out_size;        /* S of Resize(img_scale=(S, S)) */
+    int32_t n_choice;        /* entries used in crop_choice, 1..8 */
+    double crop_choice[8];   /* RandomSquareCrop(crop_choice=...); double: cw = int(scale * short) */
+    double flip_ratio;       /* RandomFlip(flip_ratio=...) */
+    float pad_value;         /* fill outside the source image (128, transforms.py:1128) */
+    uint32_t seed;
+    int32_t max_attempts;    /* window draws per scale (250, transforms.py:1058) */
+    int32_t max_retries;     /* scale re-draws before giving up (the reference loops forever) */
+    int32_t gmax;            /* rows of the padded GT outputs */
+} YunetAugCfg;
+
+/* Per image: decide scale / window / flip, transform and compact the kept boxes + keypoints.
+ *  src_hw [N,2] (h, w); boxes [sum G,4] xyxy; kps [sum G,5,3]; gt_off [N+1] prefix offsets;
+ *  params [N,8] int32 = left, top, cw (0 = failed), flip, kept, draws, status, 0
+ *      status 0 ok, 1 no window with a box centre inside (or no GT), 2 kept > gmax (truncated);
+ *  out_boxes [N,gmax,4], out_kps [N,gmax,5,3] (rows >= count zeroed), out_count [N]. */
+int yunet_aug_decide(const int32_t* src_hw, const float* boxes, const float* kps, const int32_t* gt_off,
+                     const YunetAugCfg* cfg, uint32_t iteration, int N, int32_t* params,
+                     float* out_boxes, float* out_kps, int32_t* out_count, void* stream);
+/* Crop (pad 128 outside the source) -> bilinear resize to S x S -> flip, uint8 HWC sources
+ * (src + src_off[n], BGR as loaded) to planar fp32 [N,3,S,S]; `params` from yunet_aug_decide. */
+int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t* src_hw,
+                     const int32_t* params, const YunetAugCfg* cfg, int N, float* out_img, void* stream);
+
 int yunet_abi_version(void);
 /* grid size the fused conv kernels are launched with (rows of wgrad_partials). */
 int yunet_conv_blocks(void);

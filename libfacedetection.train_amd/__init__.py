@@ -11,6 +11,7 @@ from .builder import (BACKBONES, BBOX_ASSIGNERS, DETECTORS, HEADS, LOSSES, MODEL
 from .registry import Config, ConfigDict, Registry, build_from_cfg  # noqa: F401
 from . import losses, point_generator, sim_ota_assigner  # noqa: F401,E402
 from . import yunet_backbone, tfpn, yunet_head, yunet  # noqa: F401,E402
+from . import pipelines  # noqa: F401,E402
 from .yunet import YuNet  # noqa: F401,E402
 
 __version__ = '0.1.0'

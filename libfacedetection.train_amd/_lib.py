@@ -48,6 +48,12 @@ class YunetLossCfg(C.Structure):
                 ('smooth_point', C.c_float), ('kps_beta', C.c_float)]
 
 
+class YunetAugCfg(C.Structure):
+    _fields_ = [('out_size', C.c_int32), ('n_choice', C.c_int32), ('crop_choice', C.c_double * 8),
+                ('flip_ratio', C.c_double), ('pad_value', C.c_float), ('seed', C.c_uint32),
+                ('max_attempts', C.c_int32), ('max_retries', C.c_int32), ('gmax', C.c_int32)]
+
+
 class YunetOp(C.Structure):
     _fields_ = [('opcode', C.c_int32), ('i', C.c_int32 * 12), ('f', C.c_float * 8),
                 ('p', C.c_void_p * 12), ('bn', YunetBN * 2), ('dp', YunetDP),
@@ -80,6 +86,9 @@ _SIGNATURES = {
     'yunet_bn_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     'yunet_reduce_partials_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'yunet_aug_decide': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetAugCfg), C.c_uint32, C.c_int] +
+                         [C.c_void_p] * 5),
+    'yunet_aug_pixels': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetAugCfg), C.c_int, C.c_void_p, C.c_void_p]),
     'yunet_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p]),
     'yunet_assign': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +

@@ -8,6 +8,7 @@ BBOX_ASSIGNERS = Registry('bbox_assigner')
 BBOX_SAMPLERS = Registry('bbox_sampler')
 PRIOR_GENERATORS = Registry('Generator for anchors and points')
 ANCHOR_GENERATORS = PRIOR_GENERATORS
+PIPELINES = Registry('pipeline')          # mmdet/datasets/builder.py:23
 
 
 def build_backbone(cfg):

@@ -49,6 +49,45 @@ class SyntheticWiderFace:
         return synthetic.to_device(b, device) if device is not None else b
 
 
+class SyntheticSourceImages:
+    """Synthetic DECODED sources (uint8 HWC at WIDER-like sizes, ragged GT) kept resident on the
+    device and pushed through the reference's train pipeline on the GPU (pipelines.DevicePipeline:
+    RandomSquareCrop -> Resize -> RandomFlip -> collate) every iteration -- the role of
+    RetinaFaceDataset + the cv2 worker processes, minus image decoding."""
+
+    def __init__(self, pipeline, samples_per_gpu=16, iters_per_epoch=403, rank=0, pool=64,
+                 src_hw=((768, 1024), (1024, 683), (500, 375), (683, 1024)), max_gt=synthetic.MAX_GT,
+                 seed=0, **_):
+        from .pipelines import DevicePipeline
+        self.pipe = DevicePipeline(pipeline, seed=seed + 7919 * rank, gmax=64 if max_gt <= 64 else 128)
+        self.bs, self.iters_per_epoch, self.rank = samples_per_gpu, iters_per_epoch, rank
+        self.pool, self.src_hw, self.max_gt, self.seed = pool, src_hw, max_gt, seed
+        self._src = None
+
+    def _build(self, device):
+        import numpy as np
+        from .pipelines import SourceBatch
+        rng = np.random.default_rng(self.seed + 1000 * self.rank)
+        gen = torch.Generator().manual_seed(self.seed + 1000 * self.rank)
+        imgs, boxes, kps = [], [], []
+        for i in range(self.pool):
+            h, w = self.src_hw[i % len(self.src_hw)]
+            imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+            b, _, k = synthetic.make_gt(1, h, w, gen, self.max_gt)
+            boxes.append(b[0])
+            kps.append(k[0])
+        idx = [i % self.pool for i in range(self.bs)]
+        return SourceBatch.from_lists([imgs[i] for i in idx], [boxes[i] for i in idx],
+                                      [kps[i] for i in idx], device)
+
+    def batch(self, it, device=None):
+        if device is None:
+            raise RuntimeError('SyntheticSourceImages augments on the GPU: a device is required')
+        if self._src is None:
+            self._src = self._build(device)
+        return self.pipe(self._src, it)
+
+
 def save_checkpoint(model, optimizer, path, meta):
     """Reference format: torch.save({'meta', 'state_dict', 'optimizer'})."""
     target = model.module if hasattr(model, 'module') else model

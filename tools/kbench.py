@@ -127,6 +127,45 @@ def main():
         t = timeit(lambda: K.stem_fwd(img, w, b, st), a.reps)
         by = N * (3 * 320 * 320 + 16 * 160 * 160) * 4
         print(f'stem     fwd  {t:8.4f} ms  {by / t / 1e6:8.1f} GB/s')
+    if 'aug' in a.only:
+        # device input pipeline: 256 WIDER-sized uint8 sources (768x1024) -> S x S fp32 batches.
+        # algorithmic bytes per image: the crop window read once (cw*cw*3 B, clipped to the
+        # source) + the planar fp32 output (3*S*S*4 B)
+        import numpy as np
+        from yunet_amd.pipelines import DevicePipeline, SourceBatch
+        rng = np.random.default_rng(0)
+        n, h, w = N, 768, 1024
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        gts = []
+        for _ in range(n):
+            g = int(rng.integers(1, 24))
+            x1, y1 = rng.uniform(0, w - 80, g), rng.uniform(0, h - 80, g)
+            side = rng.uniform(8, 80, g)
+            gts.append((np.stack([x1, y1, x1 + side, y1 + side], 1).astype(np.float32),
+                        np.ones((g, 5, 3), np.float32)))
+        sb = SourceBatch.from_lists([img] * n, [g[0] for g in gts], [g[1] for g in gts], DEV)
+        for S in (320, 640):
+            pipe = DevicePipeline([
+                dict(type='LoadImageFromFile', to_float32=True),
+                dict(type='LoadAnnotations', with_bbox=True, with_keypoints=True),
+                dict(type='RandomSquareCrop', crop_choice=[0.5, 0.7, 0.9, 1.1, 1.3, 1.5]),
+                dict(type='Resize', img_scale=(S, S), keep_ratio=False),
+                dict(type='RandomFlip', flip_ratio=0.5),
+                dict(type='Normalize', mean=[0., 0., 0.], std=[1., 1., 1.], to_rgb=False),
+                dict(type='DefaultFormatBundle'), dict(type='Collect', keys=['img'])], seed=1)
+            it = [0]
+
+            def run():
+                it[0] += 1
+                pipe(sb, it[0])
+            t = timeit(run, a.reps)
+            pr = pipe.params.cpu().numpy().astype(np.int64)
+            x0, y0 = np.maximum(pr[:, 0], 0), np.maximum(pr[:, 1], 0)
+            x1, y1 = np.minimum(pr[:, 0] + pr[:, 2], w), np.minimum(pr[:, 1] + pr[:, 2], h)
+            src_b = int(((x1 - x0) * (y1 - y0) * 3).sum())
+            out_b = n * 3 * S * S * 4
+            print(f'aug S={S}  {t:8.4f} ms/batch  {n / t * 1e3:10.0f} img/s  '
+                  f'{(src_b + out_b) / t / 1e6:8.1f} GB/s (src {src_b / 1e6:.0f} MB + out {out_b / 1e6:.0f} MB)')
 
 
 if __name__ == '__main__':

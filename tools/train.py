@@ -69,11 +69,15 @@ def main():
     model = yunet_amd.build_detector(cfg.model)
     model.init_weights()
     dcfg = cfg.data.train
-    if dcfg.get('type') != 'SyntheticWiderFace':
-        raise SystemExit('only the SyntheticWiderFace data source is available: the WIDER/cv2 '
-                         'pipeline of the reference is outside the accelerated path')
-    ds = R.SyntheticWiderFace(samples_per_gpu=cfg.data.samples_per_gpu, rank=rank,
-                              **{k: v for k, v in dcfg.items() if k != 'type'})
+    kw = {k: v for k, v in dcfg.items() if k != 'type'}
+    if dcfg.get('type') == 'SyntheticWiderFace':
+        ds = R.SyntheticWiderFace(samples_per_gpu=cfg.data.samples_per_gpu, rank=rank, **kw)
+    elif dcfg.get('type') == 'SyntheticSourceImages':      # device-side reference pipeline
+        ds = R.SyntheticSourceImages(samples_per_gpu=cfg.data.samples_per_gpu, rank=rank, seed=seed, **kw)
+    else:
+        raise SystemExit('data sources: SyntheticWiderFace (ready batches) or SyntheticSourceImages '
+                         '(decoded sources + the reference train pipeline on the GPU); reading and '
+                         'decoding the WIDER files is outside the accelerated path')
     meta = dict(config=args.config, seed=seed, CLASSES=('face',))
     R.train_detector(model, ds, cfg, distributed=distributed, validate=False, meta=meta,
                      max_iters=args.max_iters)
