@@ -123,7 +123,9 @@ int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C
  * {stats offset (doubles, into stats_base), C, count, running offset (floats),
  *  dgamma offset, dbeta offset (floats, into grad_base)}.
  * mode 0: running_mean/var update from the forward sums at stats_base + off;
- * mode 1: d(gamma), d(beta) from the backward sums at stats_base + off. */
+ * mode 1: d(gamma), d(beta) from the backward sums at stats_base + off;
+ * mode 2: eval() -- WRITES sums at stats_base + off whose mean / variance equal the running
+ *         statistics, so the same forward kernels apply BatchNorm in eval mode. */
 int yunet_bn_batch(const int32_t* table, int n, const double* stats_base, float* running_mean,
                    float* running_var, float momentum, float* grad_base, int mode, void* stream);
 
@@ -229,6 +231,17 @@ typedef struct YunetOp {
     YunetLossCfg loss;
 } YunetOp;
 int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
+
+/* ---- detection post-processing -------------------------------------
+ * YuNet_Head.get_bboxes (mmdet/models/dense_heads/yunet_head.py:290-416): priors, sigmoid scores
+ * (cls * obj) >= score_thr, _bbox_decode, then mmcv.ops.batched_nms for the single face class =
+ * greedy NMS (IoU with offset 0, suppress when IoU > iou_thr), survivors in descending score.
+ *  flat [N,P,16] raw head outputs of an eval-mode forward; P <= 16384.
+ *  dets [N,max_out,5] = x1 y1 x2 y2 score; kps [N,max_out,10] decoded landmarks or NULL
+ *  (_kps_decode, yunet_head.py:388-393); count [N]; scratch >= N*P*16 bytes. */
+int yunet_detect(const float* flat, const YunetLevels* lv, int N, int P, float score_thr,
+                 float iou_thr, int max_out, float* dets, float* kps, int32_t* count, void* scratch,
+                 void* stream);
 
 /* ---- device input pipeline ----------------------------------------
  * The reference's TRAIN pipeline (configs/yunet_n.py:36-56) on the device:

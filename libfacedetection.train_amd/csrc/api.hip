@@ -38,9 +38,17 @@ __global__ void bn_batch_kernel(const int32_t* __restrict__ table, const double*
             float* v = rv + t[3];
             m[c] = (1.0f - momentum) * m[c] + momentum * (float)mean;
             v[c] = (1.0f - momentum) * v[c] + momentum * (float)unb;
-        } else {
+        } else if (mode == 1) {
             grad_base[t[5] + c] = (float)st[c];        // d(beta)  = sum dy
             grad_base[t[4] + c] = (float)st[C + c];    // d(gamma) = sum dy * xhat
+        } else {
+            // mode 2, eval(): synthesise the sums whose mean / biased variance are the RUNNING
+            // statistics, so the train-mode kernels (which derive their coefficients from the
+            // producer's sums) apply nn.BatchNorm2d in eval mode unchanged
+            double* w = const_cast<double*>(st);
+            const double m = (double)rm[t[3] + c], v = (double)rv[t[3] + c];
+            w[c] = m * (double)count;
+            w[C + c] = (v + m * m) * (double)count;
         }
     }
 }

@@ -344,6 +344,23 @@ class Plan:
         self.c_fwd_b = self._carray(self.fwd_b)
         self.c_bwd = self._carray(self.bwd)
 
+        # ---- eval(): the same conv-stack launches with BatchNorm on the running statistics
+        # (op 0 fills the sums from running_mean / running_var instead of zeroing them; producers
+        # do not accumulate: ConvDPUnits get out_has_bn = 0, the stem sums into a scratch block)
+        self.eval_scratch = torch.zeros(64, device=dev, dtype=torch.float64)
+        self.fwd_eval = [self._op(L.OP_BN_BATCH, p=[self.bn_table_f.data_ptr(), self.stats.data_ptr(),
+                                                    fp.running_mean.data_ptr(), fp.running_var.data_ptr(), None],
+                                  i=[len(rows_f), 2], f=[0.0])]
+        for op in self.fwd_a[1:]:
+            cp = L.YunetOp()
+            C.memmove(C.byref(cp), C.byref(op), C.sizeof(L.YunetOp))
+            if cp.opcode == L.OP_DP_FWD:
+                cp.dp.out_has_bn = 0
+            elif cp.opcode == L.OP_STEM_FWD:
+                cp.p[4] = self.eval_scratch.data_ptr()
+            self.fwd_eval.append(cp)
+        self.c_fwd_eval = self._carray(self.fwd_eval)
+
     # ------------------------------------------------------------------ helpers
     bn_count = None
 
@@ -525,6 +542,8 @@ class Plan:
         for which, idx in self.img_ptr_ops:
             arr = {'fwd_a': self.c_fwd_a, 'bwd': self.c_bwd}[which]
             arr[idx].p[0] = ptr
+            if which == 'fwd_a':
+                self.c_fwd_eval[idx].p[0] = ptr       # same position: op 0 is replaced, not removed
 
 
 class YuNetEngine:
@@ -625,6 +644,19 @@ class YuNetEngine:
                                             async_op=async_op)
 
     # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def forward_eval(self, img):
+        """eval(): conv stack with BatchNorm on the running statistics -> flat [N,P,16]
+        (cls | dx dy dw dh | obj | 10 kps raw head outputs).  No statistics are updated."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        n, _, h, w = img.shape
+        plan = self.get_plan(n, h, w, 1)
+        self.plan = plan
+        self._img = img
+        plan.set_img(img)
+        self._exec(plan.c_fwd_eval, 'yunet_exec(fwd_eval)')
+        return plan.flat
+
     @torch.no_grad()
     def forward_features(self, img):
         """Train-mode conv stack only -> flat [N,P,16] (used by tests)."""

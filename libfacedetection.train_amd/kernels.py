@@ -229,6 +229,24 @@ def make_levels(sizes, strides):
     return lv
 
 
+def detect(flat, sizes, strides, score_thr=0.02, iou_thr=0.45, max_out=None, with_kps=True):
+    """flat [N,P,16] raw head outputs -> (dets [N,max_out,5], kps [N,max_out,10] or None, count [N]).
+    Rows at or beyond count[i] are unspecified."""
+    _chk_f32(flat)
+    n, p = flat.shape[0], flat.shape[1]
+    max_out = p if max_out is None or max_out < 0 else int(max_out)
+    dev = flat.device
+    dets = torch.empty(n, max_out, 5, device=dev, dtype=torch.float32)
+    kps = torch.empty(n, max_out, 10, device=dev, dtype=torch.float32) if with_kps else None
+    count = torch.empty(n, device=dev, dtype=torch.int32)
+    scratch = torch.empty(n, p, 4, device=dev, dtype=torch.float32)
+    lv = make_levels(sizes, strides)
+    L.check(L.load().yunet_detect(_p(flat), C.byref(lv), n, p, float(score_thr), float(iou_thr), max_out,
+                                  _p(dets), _p(kps) if with_kps else None, _p(count), _p(scratch), _stream()),
+            'yunet_detect')
+    return dets, kps, count
+
+
 def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.1,
                   box_eps=1e-6, smooth_point=0.1, kps_beta=1.0 / 9.0):
     c = L.YunetLossCfg()

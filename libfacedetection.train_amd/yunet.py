@@ -115,10 +115,28 @@ class YuNet(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     def forward_test(self, imgs, img_metas, **kwargs):
-        raise NotImplementedError('test-time decode + NMS is the next scope row (SURVEY.md 8f); '
-                                  'use feature_test(img) for raw prediction maps')
+        """mmdet/models/detectors/base.py:132-167: lists of length 1 (no test-time augmentation)."""
+        if isinstance(imgs, (list, tuple)):
+            if len(imgs) != 1:
+                raise NotImplementedError('aug_test (multi-scale / flip testing) is not built')
+            imgs, img_metas = imgs[0], img_metas[0]
+        return self.simple_test(imgs, img_metas, **kwargs)
 
-    simple_test = forward_test
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, rescale=False, with_landmarks=False):
+        """mmdet/models/detectors/yunet.py:53-81: eval-mode forward -> get_bboxes -> bbox2result:
+        per image a one-element list (one class) with an [n, 5] float32 array
+        (x1, y1, x2, y2, score), descending score.  with_landmarks=True also returns the decoded
+        5-point landmarks [n, 10] per image."""
+        if self.training:
+            raise RuntimeError('simple_test requires model.eval() (BatchNorm on running statistics)')
+        if not img.is_cuda:
+            raise RuntimeError('YuNet.simple_test needs a CUDA (ROCm) tensor: HIP kernels only, no CPU fallback')
+        eng = self._ensure_engine(img.device)
+        flat = eng.forward_eval(img.float().contiguous())
+        res, lmk = self.bbox_head.get_bboxes_flat(flat, eng.plan.sizes, img_metas, rescale=rescale)
+        out = [[d.cpu().numpy()] for d, _ in res]                  # bbox2result, num_classes = 1
+        return (out, [k.cpu().numpy() for k in lmk]) if with_landmarks else out
 
     # ------------------------------------------------------------------ engine binding
     def arch(self):

@@ -174,6 +174,40 @@ class YuNet_Head(nn.Module):
         self.last_gt_inds = gi
         return dict(loss_cls=l_cls, loss_bbox=l_box, loss_obj=l_obj, loss_kps=l_kps)
 
-    def get_bboxes(self, *args, **kwargs):
-        raise NotImplementedError('inference post-processing (decode + NMS) is the next scope '
-                                  'row (SURVEY.md 8f); this build accelerates the training path')
+    def get_bboxes(self, cls_scores, bbox_preds, objectnesses, kps_preds, img_metas=None, cfg=None,
+                   rescale=False, with_nms=True):
+        """Same arguments / result list as yunet_head.py:290-372: per image a
+        (dets [n,5] = x1 y1 x2 y2 score in descending score, labels [n]) pair.  Decode, score
+        threshold and NMS run in one HIP kernel (csrc/detect.hip)."""
+        if not with_nms:
+            raise NotImplementedError('with_nms=False is not used by the reference test path')
+        num_imgs = cls_scores[0].shape[0]
+        sizes = [tuple(c.shape[2:]) for c in cls_scores]
+        per_level = []
+        for c, b, o, k in zip(cls_scores, bbox_preds, objectnesses, kps_preds):
+            m = torch.cat([c, b, o, k], dim=1).float()
+            per_level.append(m.permute(0, 2, 3, 1).reshape(num_imgs, -1, m.shape[1]))
+        flat = torch.cat(per_level, dim=1).contiguous()
+        return self.get_bboxes_flat(flat, sizes, img_metas, cfg, rescale)[0]
+
+    def get_bboxes_flat(self, flat, sizes, img_metas=None, cfg=None, rescale=False):
+        """flat [N,P,16] (eval-mode engine output) -> (result list, decoded landmark list)."""
+        cfg = self.test_cfg if cfg is None else cfg
+        if cfg is None:
+            raise ValueError('test_cfg (score_thr, nms.iou_threshold, max_per_img) is required')
+        nms = cfg.get('nms', dict(type='nms', iou_threshold=0.45))
+        if nms.get('type', 'nms') != 'nms':
+            raise NotImplementedError(f"nms type {nms.get('type')!r}")
+        dets, kps, count = K.detect(flat, sizes, self.strides, cfg.get('score_thr', 0.02),
+                                    nms.get('iou_threshold', 0.45), cfg.get('max_per_img', -1))
+        cnt = count.cpu().tolist()
+        results, landmarks = [], []
+        for i, c in enumerate(cnt):
+            d, k = dets[i, :c].clone(), kps[i, :c].clone()
+            if rescale:                                     # yunet_head.py:357-361
+                sf = torch.as_tensor(img_metas[i]['scale_factor'], dtype=torch.float32, device=d.device)
+                d[:, :4] /= sf
+                k /= sf[:2].repeat(5)
+            results.append((d, torch.zeros(c, dtype=torch.int64, device=d.device)))
+            landmarks.append(k)
+        return results, landmarks

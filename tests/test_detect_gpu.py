@@ -1,0 +1,184 @@
+"""-m gpu: test-time path on the device -- eval-mode forward (BatchNorm on running statistics)
+and get_bboxes (scores, threshold, decode, NMS in csrc/detect.hip) -- against fixtures from the
+unmodified reference `simple_test` and against the CPU oracle.
+
+Scores / boxes go through expf on both sides, so values are compared to 1e-5 / 1e-3 px and the
+fixtures were selected with every decision (score threshold, IoU threshold, score order) at
+least 2e-5 / 2e-5 / 2e-7 away from its boundary; detections are matched in score order."""
+import numpy as np
+import pytest
+import torch
+
+import crafted as C
+import detect_oracle as D
+from test_detect_oracle import load_case
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build_model(kind, sd):
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile(f'configs/yunet_{kind}.py')
+    model = yunet_amd.build_detector(cfg.model)
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).eval()
+
+
+def assert_same_dets(got, ref, box_atol=2e-3):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.allclose(got[:, 4], ref[:, 4], rtol=2e-5, atol=1e-7)
+    assert np.allclose(got[:, :4], ref[:, :4], rtol=1e-5, atol=box_atol)
+
+
+@pytest.mark.parametrize('name', ['detect_s_160.npz', 'detect_n_320.npz'])
+def test_simple_test_vs_reference_fixture(name):
+    g, arch, sd, img = load_case(name)
+    model = build_model(str(g['kind']), sd)
+    n = img.shape[0]
+    metas = [dict(img_shape=img.shape[2:] + (3,), scale_factor=np.ones(4, np.float32)) for _ in range(n)]
+    res, lmk = model.simple_test(img.to(DEV), metas, with_landmarks=True)
+    assert len(res) == n
+    flat, sizes = D.eval_flat(img, sd, arch)
+    oracle = D.get_bboxes(flat, sizes, arch['strides'], 0.02, 0.45)
+    for i in range(n):
+        assert len(res[i]) == 1 and res[i][0].dtype == np.float32          # bbox2result, one class
+        assert_same_dets(res[i][0], g[f'dets_{i}'])
+        assert np.allclose(lmk[i], oracle[i][1].numpy(), rtol=1e-5, atol=2e-3)
+    # forward(return_loss=False) with the mmdet list-of-one convention ends in the same place
+    res2 = model(img=[img.to(DEV)], img_metas=[metas], return_loss=False)
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(res, res2))
+    with pytest.raises(RuntimeError, match='eval'):
+        model.train().simple_test(img.to(DEV), metas)
+
+
+@pytest.mark.parametrize('kind,size,n', [('s', 160, 4), ('n', 320, 2)])
+def test_eval_forward_vs_oracle(kind, size, n):
+    """BatchNorm on running statistics through the train-mode kernels (synthesised sums)."""
+    arch, sd = D.make_state(kind, 5, size)
+    img = D.structured_images(n, size, 9)
+    model = build_model(kind, sd)
+    eng = model._ensure_engine(torch.device(DEV))
+    rm0 = eng.params.running_mean.clone()
+    flat = eng.forward_eval(img.to(DEV).contiguous()).cpu()
+    ref, _ = D.eval_flat(img, sd, arch)
+    assert float((flat - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(rm0, eng.params.running_mean), 'eval forward must not touch running statistics'
+
+
+def _run_detect(flat, h, w, **kw):
+    import yunet_amd.kernels as k
+    dets, kps, cnt = k.detect(flat.to(DEV).contiguous(), C.featmap_sizes(h, w), [8, 16, 32], **kw)
+    torch.cuda.synchronize()
+    return dets.cpu(), kps.cpu(), cnt.cpu()
+
+
+def _stable(flat, h, w):
+    ds, di, dt = D.stability(flat, C.featmap_sizes(h, w), [8, 16, 32], 0.02, 0.45)
+    return ds > 1e-5 and di > 1e-5 and dt > 1e-7
+
+
+def exact_heads(n, P, seed):
+    """Head outputs whose decoded boxes are exactly representable (dw = dh = 0 -> w = h = stride,
+    centre offsets in 1/8 steps) and whose scores are 1e-4 apart and >= 1e-3 away from the
+    threshold: every NMS decision is then bit-identical on both sides, whatever the ulp of expf."""
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(n, P, 16)
+    flat[..., 1:3] = torch.randint(-12, 13, (n, P, 2), generator=g).float() / 8.0
+    flat[..., 6:16] = torch.randint(-16, 17, (n, P, 10), generator=g).float() / 8.0
+    obj = torch.full((n, P), 9.0)
+    so = torch.sigmoid(obj)
+    target = torch.stack([torch.randperm(P, generator=g) for _ in range(n)]).float() * 1e-4 + 0.0215
+    low = torch.rand(n, P, generator=g) < 0.25                      # a quarter below the threshold
+    target[low] = target[low] * 0.02 + 0.001
+    target = target.clamp(max=0.97)
+    flat[..., 0] = torch.logit((target / so).clamp(1e-6, 1 - 1e-6))
+    flat[..., 5] = obj
+    return flat
+
+
+@pytest.mark.parametrize('h,n,seed', [(160, 6, 1), (320, 3, 2), (640, 2, 3)])
+def test_detect_kernel_vs_oracle_exact_geometry(h, n, seed):
+    """Thousands of candidates per image with heavy overlap (K exceeds the LDS box cache at 640):
+    the survivors, their order and their boxes must be identical to the oracle's."""
+    sizes = C.featmap_sizes(h, h)
+    P = sum(a * b for a, b in sizes)
+    flat = exact_heads(n, P, seed)
+    dets, kps, cnt = _run_detect(flat, h, h)
+    ref = D.get_bboxes(flat, sizes, [8, 16, 32], 0.02, 0.45)
+    for i in range(n):
+        c = int(cnt[i])
+        assert c == len(ref[i][0]), (i, c, len(ref[i][0]))
+        assert torch.equal(dets[i, :c, :4], ref[i][0][:, :4]), f'boxes / order differ (image {i})'
+        assert torch.allclose(dets[i, :c, 4], ref[i][0][:, 4], rtol=2e-5, atol=1e-7)
+        assert torch.equal(kps[i, :c], ref[i][1])
+    cand = int(((flat[..., 0].sigmoid() * flat[..., 5].sigmoid()) >= 0.02).sum())
+    assert int(cnt.sum()) < 0.95 * cand and int(cnt.max()) > 100      # some suppression (heavy: fixtures)
+
+
+def test_detect_kernel_vs_oracle_random_heads():
+    """Unconstrained random head outputs (boxes from 0.3x to 8x the stride) on a draw whose
+    decisions are away from their thresholds."""
+    h, n = 160, 6
+    P = sum(a * b for a, b in C.featmap_sizes(h, h))
+    g = torch.Generator().manual_seed(4)
+    for attempt in range(40):
+        flat = torch.randn(n, P, 16, generator=g)
+        flat[..., 0] = flat[..., 0] * 2.0 - 1.5
+        flat[..., 3:5] = flat[..., 3:5] * 0.7 + 0.6
+        if _stable(flat, h, h):
+            break
+    else:
+        pytest.skip('no stable random draw')
+    dets, kps, cnt = _run_detect(flat, h, h)
+    ref = D.get_bboxes(flat, C.featmap_sizes(h, h), [8, 16, 32], 0.02, 0.45)
+    for i in range(n):
+        c = int(cnt[i])
+        assert c == len(ref[i][0]), (i, c, len(ref[i][0]))
+        assert_same_dets(dets[i, :c].numpy(), ref[i][0].numpy())
+        assert np.allclose(kps[i, :c].numpy(), ref[i][1].numpy(), rtol=1e-5, atol=2e-3)
+
+
+def test_detect_edge_cases():
+    h = 160
+    P = sum(a * b for a, b in C.featmap_sizes(h, h))
+    # nothing above the threshold -> count 0
+    flat = torch.zeros(2, P, 16)
+    flat[..., 0] = -10.0
+    _, _, cnt = _run_detect(flat, h, h)
+    assert cnt.tolist() == [0, 0]
+    # identical boxes everywhere on one level: one survivor per distinct box; max_out truncates
+    flat = torch.zeros(1, P, 16)
+    flat[..., 0] = torch.linspace(3.0, -1.0, P)          # strictly decreasing scores
+    flat[..., 5] = 4.0
+    flat[..., 3:5] = 5.0                                  # huge boxes: everything overlaps
+    dets, _, cnt = _run_detect(flat, h, h)
+    ref = D.get_bboxes(flat, C.featmap_sizes(h, h), [8, 16, 32], 0.02, 0.45)
+    assert int(cnt[0]) == len(ref[0][0])
+    dets2, _, cnt2 = _run_detect(flat, h, h, max_out=3)
+    assert int(cnt2[0]) == min(3, int(cnt[0]))
+    assert torch.equal(dets2[0, :int(cnt2[0])], dets[0, :int(cnt2[0])])
+    # P larger than the kernel's key array is rejected, like any unsupported shape
+    import yunet_amd.kernels as k
+    from yunet_amd._lib import YunetHipError
+    with pytest.raises(YunetHipError):
+        k.detect(torch.zeros(1, 1280 * 1280 // 64 + 1280 * 1280 // 256 + 1280 * 1280 // 1024, 16, device=DEV),
+                 C.featmap_sizes(1280, 1280), [8, 16, 32])
+
+
+def test_detect_full_batch_properties():
+    """BASELINE batch (256 x 320x320): survivors are sorted, pairwise IoU <= thr, every dropped
+    candidate overlaps a higher-scored survivor (the defining properties of greedy NMS)."""
+    h, n = 320, 256
+    P = sum(a * b for a, b in C.featmap_sizes(h, h))
+    flat = exact_heads(n, P, 5)
+    dets, _, cnt = _run_detect(flat, h, h)
+    assert int(cnt.min()) > 0
+    for i in (0, 17, 255):
+        c = int(cnt[i])
+        d = dets[i, :c]
+        assert bool((d[:-1, 4] >= d[1:, 4]).all())
+        for j in range(min(c - 1, 40)):
+            assert float(D.nms_iou(d[j, :4], d[j + 1:, :4]).max()) <= 0.45 + 1e-6
+        ref = D.get_bboxes(flat[i:i + 1], C.featmap_sizes(h, h), [8, 16, 32], 0.02, 0.45)[0][0]
+        assert torch.equal(d[:, :4], ref[:, :4])

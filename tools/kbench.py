@@ -166,6 +166,31 @@ def main():
             out_b = n * 3 * S * S * 4
             print(f'aug S={S}  {t:8.4f} ms/batch  {n / t * 1e3:10.0f} img/s  '
                   f'{(src_b + out_b) / t / 1e6:8.1f} GB/s (src {src_b / 1e6:.0f} MB + out {out_b / 1e6:.0f} MB)')
+    if 'det' in a.only:
+        # test-time path: eval-mode forward of YuNet_n on 256 x 320x320 + get_bboxes (one workgroup
+        # per image: scores, bitonic sort of the candidates, greedy NMS)
+        import yunet_amd
+        cfg = yunet_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                     'configs', 'yunet_n.py'))
+        torch.manual_seed(0)
+        model = yunet_amd.build_detector(cfg.model).to(DEV).eval()
+        img = torch.rand(N, 3, 320, 320, device=DEV) * 255
+        eng = model._ensure_engine(torch.device(DEV))
+        t = timeit(lambda: eng.forward_eval(img), a.reps)
+        print(f'eval fwd {t:8.4f} ms/batch  {N / t * 1e3:10.0f} img/s')
+        P = 2100
+        sizes = [(40, 40), (20, 20), (10, 10)]
+        g = torch.Generator(device='cpu').manual_seed(0)
+        for label, shift in (('sparse', -7.0), ('medium', -4.5), ('dense', 0.0)):
+            flat = torch.randn(N, P, 16, generator=g)
+            flat[..., 0] = flat[..., 0] * 1.5 + shift
+            flat[..., 3:5] = flat[..., 3:5] * 0.5 + 0.8
+            flat = flat.to(DEV)
+            t = timeit(lambda: K.detect(flat, sizes, [8, 16, 32]), a.reps)
+            _, _, cnt = K.detect(flat, sizes, [8, 16, 32])
+            cand = int(((flat[..., 0].sigmoid() * flat[..., 5].sigmoid()) >= 0.02).sum()) / N
+            print(f'detect   {t:8.4f} ms/batch  {N / t * 1e3:10.0f} img/s  {label}: {cand:.0f} candidates '
+                  f'-> {float(cnt.float().mean()):.0f} kept per image')
 
 
 if __name__ == '__main__':
