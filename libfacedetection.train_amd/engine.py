@@ -17,7 +17,6 @@ PyTorch supplies device memory, streams and torch.distributed only.
 import ctypes as C
 import math
 
-import numpy as np
 import torch
 
 from . import _lib as L

@@ -13,7 +13,6 @@ import torch.nn as nn
 
 from .builder import DETECTORS, build_backbone, build_head, build_neck
 from .engine import YuNetEngine
-from .registry import ConfigDict
 
 
 class LazyScalar:
@@ -223,19 +222,31 @@ class YuNet(nn.Module):
         log_vars = OrderedDict((k, v.mean()) for k, v in losses.items())
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         vec = torch.stack([v.detach() for v in log_vars.values()] + [loss.detach()])
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            vec = vec / torch.distributed.get_world_size()
-            torch.distributed.all_reduce(vec)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         host = getattr(self, '_log_host', None)
         if host is None or not vec.is_cuda:
+            if dist_on:
+                vec = vec / torch.distributed.get_world_size()
+                torch.distributed.all_reduce(vec)
             vals = vec.cpu().tolist()
             out = OrderedDict(zip(list(log_vars) + ['loss'], vals))
             return loss, out
         row = host[self._log_iter % host.shape[0]]     # ring: values stay valid for 256 iters
         self._log_iter += 1
-        row[:vec.numel()].copy_(vec, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # the world average of the logged scalars and their copy to the host run on a side
+        # stream: the backward pass that follows on the main stream never waits for them
+        side = getattr(self, '_log_stream', None)
+        if side is None:
+            side = self._log_stream = torch.cuda.Stream(device=vec.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            if dist_on:
+                vec = vec / torch.distributed.get_world_size()
+                torch.distributed.all_reduce(vec)
+            row[:vec.numel()].copy_(vec, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        vec.record_stream(side)
         out = OrderedDict((k, LazyScalar(row, i, ev))
                           for i, k in enumerate(list(log_vars) + ['loss']))
         return loss, out
