@@ -59,7 +59,8 @@ def main():
             dst.copy_(src)
         torch.cuda.synchronize()
     cases = [('dp64', 64, 64, 80, 80), ('dp16', 16, 16, 160, 160), ('dp16_64', 16, 64, 80, 80),
-             ('dp64_40', 64, 64, 40, 40), ('head', 64, 16, 40, 40)]
+             ('dp64_40', 64, 64, 40, 40), ('head', 64, 16, 40, 40),
+             ('dp64_20', 64, 64, 20, 20), ('dp64_10', 64, 64, 10, 10), ('head_10', 64, 16, 10, 10)]
     for name, ci, co, h, w in cases:
         if a.only and a.only not in name:
             continue

@@ -25,4 +25,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_FETCH_SIZE.csv $OUT/${R}_pmc_WRITE_SIZE.csv $OUT/${R}_pmc_traffic.json
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_calib_FETCH_SIZE.csv $OUT/${R}_pmc_calib_WRITE_SIZE.csv $OUT/${R}_pmc_calib.json
+#   4. utilisation of the dominant kernels (derived metrics, one per pass): MFMA / VALU / LDS
+UT=""
+for c in MfmaUtil VALUBusy LdsUtil LDSBankConflict; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/util_${R}_$c -o p -- \
+      python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 > /tmp/util_$c.log 2>&1
+  for f in $(find /tmp/util_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_util_$c.csv; UT="$UT $OUT/${R}_util_$c.csv"; done
+done
+python $GRAFT_REPO_ROOT/tools/pmc_mean.py $OUT/${R}_util.json $UT
 ls -la $OUT | tail -8
