@@ -11,6 +11,8 @@
 // once and writes its output once (SURVEY.md 8d "unit-boundary traffic").
 #include <cstdlib>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -443,6 +445,8 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
             nb = 1;
         blocks_per_cu = nb > 4 ? 4 : nb;
+        if (const char* e = getenv("YUNET_DP_FWD_BLOCKS_PER_CU"))   // occupancy experiments only
+            if (atoi(e) >= 1 && atoi(e) <= blocks_per_cu) blocks_per_cu = atoi(e);
     }
     // persistent grid: exactly the resident workgroups, so every one pipelines many tiles
     const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
