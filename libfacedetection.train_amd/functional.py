@@ -71,3 +71,9 @@ def stem(m, x):
 def max_pool2(x):
     # plain F.max_pool2d on already-activated maps is plumbing; keep it in torch
     return torch.nn.functional.max_pool2d(x, 2)
+
+
+@torch.no_grad()
+def upsample2_add(fine, coarse):
+    """fine + nearest-neighbour 2x upsampling of coarse (the TFPN merge; plumbing, kept in torch)."""
+    return fine + torch.nn.functional.interpolate(coarse, scale_factor=2.0, mode='nearest')

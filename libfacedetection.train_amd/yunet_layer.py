@@ -12,18 +12,27 @@ import torch.nn as nn
 from . import functional as Fh
 
 
+def _pointwise(cin, cout):
+    return nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0, groups=1, bias=True)
+
+
+def _depthwise(c):
+    return nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1, groups=c, bias=True)
+
+
 class ConvDPUnit(nn.Module):
-    """1x1 pointwise conv (bias) -> 3x3 depthwise conv (bias, pad 1) [-> BN -> ReLU]."""
+    """Pointwise 1x1 (`conv1`) then depthwise 3x3 (`conv2`), both with bias; optional
+    BatchNorm (`bn`) + ReLU behind them."""
 
     def __init__(self, in_channels, out_channels, withBNRelu=True):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.conv1 = nn.Conv2d(in_channels, out_channels, 1, 1, 0, bias=True, groups=1)
-        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1, bias=True,
-                               groups=out_channels)
-        self.withBNRelu = withBNRelu
-        if withBNRelu:
-            self.bn = nn.BatchNorm2d(out_channels)
+        self.in_channels = int(in_channels)
+        self.out_channels = int(out_channels)
+        self.withBNRelu = bool(withBNRelu)
+        self.conv1 = _pointwise(self.in_channels, self.out_channels)
+        self.conv2 = _depthwise(self.out_channels)
+        if self.withBNRelu:
+            self.bn = nn.BatchNorm2d(self.out_channels)
             self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
@@ -31,15 +40,17 @@ class ConvDPUnit(nn.Module):
 
 
 class Conv_head(nn.Module):
-    """3x3 stride-2 conv -> BN -> ReLU -> ConvDPUnit (the stem)."""
+    """The stem: dense 3x3 stride-2 conv (`conv1`) + `bn1` + ReLU, then a ConvDPUnit (`conv2`)."""
 
     def __init__(self, in_channels, mid_channels, out_channels):
         super().__init__()
         self.in_channels, self.mid_channels, self.out_channels = \
-            in_channels, mid_channels, out_channels
-        self.conv1 = nn.Conv2d(in_channels, mid_channels, 3, 2, 1, bias=True, groups=1)
-        self.conv2 = ConvDPUnit(mid_channels, out_channels, True)
-        self.bn1 = nn.BatchNorm2d(mid_channels)
+            int(in_channels), int(mid_channels), int(out_channels)
+        self.conv1 = nn.Conv2d(self.in_channels, self.mid_channels, kernel_size=3, stride=2, padding=1,
+                               groups=1, bias=True)
+        # registration order = state_dict order of the reference: conv1, conv2, bn1
+        self.conv2 = ConvDPUnit(self.mid_channels, self.out_channels, withBNRelu=True)
+        self.bn1 = nn.BatchNorm2d(self.mid_channels)
         self.relu1 = nn.ReLU(inplace=True)
 
     def forward(self, x):
@@ -47,27 +58,31 @@ class Conv_head(nn.Module):
 
 
 class Conv4layerBlock(nn.Module):
+    """Two ConvDPUnits: `conv1` keeps the width, `conv2` changes it."""
+
     def __init__(self, in_channels, out_channels, withBNRelu=True):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.conv1 = ConvDPUnit(in_channels, in_channels, True)
-        self.conv2 = ConvDPUnit(in_channels, out_channels, withBNRelu)
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.conv1 = ConvDPUnit(self.in_channels, self.in_channels, withBNRelu=True)
+        self.conv2 = ConvDPUnit(self.in_channels, self.out_channels, withBNRelu=withBNRelu)
 
     def forward(self, x):
         return self.conv2(self.conv1(x))
 
 
 def yunet_init_weights(module):
-    """The init every YuNet component applies to itself
+    """The initialisation every YuNet component applies to itself
     (mmdet/models/backbones/yunet_backbone.py:21-31, necks/tfpn.py:21-31,
-    dense_heads/yunet_head.py:158-168)."""
-    for m in module.modules():
-        if isinstance(m, nn.Conv2d):
-            if m.bias is not None:
-                nn.init.xavier_normal_(m.weight.data)
-                m.bias.data.fill_(0.02)
-            else:
-                m.weight.data.normal_(0, 0.01)
-        elif isinstance(m, nn.BatchNorm2d):
-            m.weight.data.fill_(1)
-            m.bias.data.zero_()
+    dense_heads/yunet_head.py:158-168): Xavier-normal weights and 0.02 biases for biased
+    convolutions, N(0, 0.01) for bias-free ones, identity BatchNorm affine."""
+    convs = [m for m in module.modules() if isinstance(m, nn.Conv2d)]
+    norms = [m for m in module.modules() if isinstance(m, nn.BatchNorm2d)]
+    for conv in convs:
+        if conv.bias is None:
+            conv.weight.data.normal_(0, 0.01)
+            continue
+        nn.init.xavier_normal_(conv.weight.data)
+        conv.bias.data.fill_(0.02)
+    for bn in norms:
+        bn.weight.data.fill_(1)
+        bn.bias.data.zero_()
