@@ -148,6 +148,13 @@ class YuNet_Head(nn.Module):
 
     # ------------------------------------------------------------------ loss
     def loss_cfg(self):
+        # the fused kernel implements the reductions of the shipped configs (yunet_head.py:506-532)
+        for name, want in (('loss_cls', 'sum'), ('loss_bbox', 'sum'), ('loss_obj', 'sum'), ('loss_kps', 'mean')):
+            got = getattr(getattr(self, name), 'reduction', want)
+            if got != want:
+                raise NotImplementedError(f"{name}.reduction={got!r}: the fused loss step implements "
+                                          f"reduction={want!r} (normalised by num_pos / the keypoint "
+                                          'weight sum inside the kernel)')
         box = type(self.loss_bbox).__name__
         return K.make_loss_cfg(box, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
                                self.loss_obj.loss_weight, self.loss_kps.loss_weight,
