@@ -161,3 +161,37 @@ def test_checkpoint_roundtrip(tmp_path):
     assert meta['epoch'] == 3
     for k, v in m.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k])
+
+
+def test_device_pipeline_builds_from_reference_style_config_and_rejects_variants():
+    """The PIPELINES registry accepts the reference's train pipeline list unchanged; variants the
+    device stage does not implement fail at build time, not silently at run time."""
+    import yunet_amd
+    from yunet_amd.pipelines import DevicePipeline
+    cfg = yunet_amd.Config.fromfile('configs/yunet_n.py')
+    pipe = DevicePipeline(cfg.data.train.pipeline, seed=3, gmax=128)
+    assert pipe.out_size == 320 and pipe.cfg.n_choice == 6 and pipe.cfg.gmax == 128
+    assert list(pipe.cfg.crop_choice)[:6] == [0.5, 0.7, 0.9, 1.1, 1.3, 1.5]
+    assert pipe.cfg.flip_ratio == 0.5 and pipe.cfg.pad_value == 128.0 and pipe.cfg.max_attempts == 250
+    base = [dict(p) for p in cfg.data.train.pipeline]
+
+    def variant(i, **kw):
+        v = [dict(p) for p in base]
+        v[i].update(kw)
+        return v
+    for bad in (variant(3, keep_ratio=True), variant(3, img_scale=(320, 256)), variant(3, img_scale=(300, 300)),
+                variant(4, direction='vertical'), variant(5, mean=[104., 117., 123.]), variant(5, to_rgb=True),
+                variant(2, crop_choice=None, crop_ratio_range=(0.3, 1.0)), base[:-1], base[::-1]):
+        with pytest.raises((NotImplementedError, ValueError)):
+            DevicePipeline(bad)
+    with pytest.raises(NotImplementedError, match='DevicePipeline'):
+        pipe.steps[2](dict())                      # the carriers have no per-sample CPU implementation
+
+
+def test_loss_reduction_is_validated_for_the_fused_path():
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile('configs/yunet_s.py')
+    cfg.model.bbox_head.loss_bbox.reduction = 'mean'
+    model = yunet_amd.build_detector(cfg.model)
+    with pytest.raises(NotImplementedError, match='loss_bbox.reduction'):
+        model.bbox_head.loss_cfg()
