@@ -195,3 +195,29 @@ def test_loss_reduction_is_validated_for_the_fused_path():
     model = yunet_amd.build_detector(cfg.model)
     with pytest.raises(NotImplementedError, match='loss_bbox.reduction'):
         model.bbox_head.loss_cfg()
+
+
+def test_bench_byte_model_matches_survey_figures():
+    """bench.py's algorithmic-bytes model over the real op lists reproduces SURVEY.md 8(d):
+    YuNet_n 320x320 = 26.43 MB forward + 40.51 MB backward per image (unit-boundary traffic)."""
+    import importlib.util
+    import os
+    import yunet_amd._lib as L
+    import yunet_amd.engine as E
+    spec = importlib.util.spec_from_file_location(
+        'bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 4
+    plan = E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(n, 320, 320, 3)
+    conv = (L.OP_STEM_FWD, L.OP_DP_FWD, L.OP_POOL_FWD, L.OP_UPADD_FWD)
+    fwd = sum(bench.op_bytes(op, L) for op in plan.fwd_a if op.opcode in conv)
+    bwd = sum(bench.op_bytes(op, L) for op in plan.bwd)
+    assert fwd / n / 1e6 == pytest.approx(26.43, rel=0.02)
+    assert bwd / n / 1e6 == pytest.approx(40.51, rel=0.02)
+    # 135.6 M MAC forward per image, 76.5 % of it in the pointwise GEMMs (SURVEY 8a A1)
+    pw_flops = sum(bench.op_flops(op, L) for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
+    assert pw_flops / n / 2 / 1e6 == pytest.approx(135.6 * 0.765, rel=0.03)
+    # the committed PMC table is found and keyed by the names bench.py prints
+    traffic, src = bench.pmc_traffic('dp_bwd_kernel<64,64,8,16>')
+    assert traffic is not None and traffic > 1e8 and src.endswith('_pmc_traffic.json')
