@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/yunet_hip.h"
 
@@ -75,6 +76,59 @@ __device__ __forceinline__ float bn_dz(float dy, float z, float mean_hi, float m
 
 __device__ __forceinline__ float bnrelu(float x, float mean, float scale, float beta) {
     return fmaxf(fmaf(x - mean, scale, beta), 0.0f);
+}
+
+// Small feature maps (the 20x20 / 10x10 pyramid levels) waste most of an 8x16 tile per image.
+// For them the tile grid is laid over a virtual CANVAS on which the images of the batch sit side
+// by side, R per row, one zero gap column / row between neighbours (pitch = size + 1): a tile then
+// covers pieces of several images, the gap pixels play the role of the zero padding, and
+// pk_locate maps a canvas pixel back to (image, y, x).  `on` = 0 keeps the per-image tiling.
+struct PackGeom {
+    int on, H, W, ph, pw, R, N, CH, CW;
+    float inv_ph, inv_pw;
+};
+static inline PackGeom make_pack(int N, int H, int W) {
+    PackGeom g;
+    g.on = (H <= 20 && W <= 20 && N >= 4) ? 1 : 0;
+    g.H = H; g.W = W; g.N = N;
+    g.ph = H + 1; g.pw = W + 1;
+    g.R = N < 16 ? N : 16;
+    g.CW = g.R * g.pw;
+    g.CH = ((N + g.R - 1) / g.R) * g.ph;
+    g.inv_ph = 1.0f / (float)g.ph;
+    g.inv_pw = 1.0f / (float)g.pw;
+    return g;
+}
+// The decision depends on (N, H, W) only, so that yunet_dp_bwd_blocks() and the launch agree on the
+// grid.  Packed tensors are addressed with 32-bit byte offsets over the WHOLE tensor: the launch
+// rejects the (absurd for <= 20x20 maps) case of more than 2^30 elements.
+static inline PackGeom dp_pack_geom(int N, int H, int W) {
+    PackGeom g = make_pack(N, H, W);
+    if (getenv("YUNET_NO_PACK")) g.on = 0;    // A/B switch (tools/kbench.py)
+    return g;
+}
+// the packed kernels are instantiated for the units that live on the small pyramid levels
+static inline bool dp_use_pack(int N, int H, int W, int cin, int cout) {
+    return cin == 64 && (cout == 64 || cout == 16) && dp_pack_geom(N, H, W).on;
+}
+// backward: measured per-launch on MI355X the packed 64->16 unit wins (25.9 -> 21.5 us at 10x10),
+// the packed 64->64 one does not yet (its canvas mapping pushes the kernel into scratch), so the
+// latter keeps the per-image tiling
+static inline bool dp_use_pack_bwd(int N, int H, int W, int cin, int cout) {
+    return cout == 16 && dp_use_pack(N, H, W, cin, cout);
+}
+static inline bool dp_pack_fits(const PackGeom& g, long long x_img_stride, long long z_img_stride) {
+    const long long lim = 1ll << 30;           // floats
+    return !g.on || ((long long)g.N * x_img_stride < lim && (long long)g.N * z_img_stride < lim);
+}
+__device__ __forceinline__ bool pk_locate(const PackGeom& g, int Y, int X, int& n, int& y, int& x) {
+    if ((unsigned)Y >= (unsigned)g.CH || (unsigned)X >= (unsigned)g.CW) return false;
+    // (Y + 0.5) / pitch is at least 0.5 / pitch away from an integer: the float quotient is exact
+    const int iy = (int)(((float)Y + 0.5f) * g.inv_ph), ix = (int)(((float)X + 0.5f) * g.inv_pw);
+    y = Y - iy * g.ph;
+    x = X - ix * g.pw;
+    n = iy * g.R + ix;
+    return y < g.H && x < g.W && n < g.N;
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {

@@ -70,8 +70,8 @@ __device__ __forceinline__ float tin(float x, float mean, float scale, float bet
     return fmaxf(fmaf(x - mean, scale, beta), floor_);
 }
 
-template <int CIN, int COUT, int TH, int TW>
-__global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
+template <int CIN, int COUT, int TH, int TW, bool PACKED>
+__global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, const PackGeom pk) {
     using G = BwdGeom<CIN, COUT, TH, TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -152,9 +152,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     const int w1_ci0 = (w1_grp / (G::NTO / G::NB)) * 16 * G::MB;   // first ci / co of the wave's block
     const int w1_co0 = (w1_grp % (G::NTO / G::NB)) * 16 * G::NB;
 
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    // per-image tiling, or (PACKED) one tile grid over the packed canvas of all images (common.h)
+    const int tiles_x = ((PACKED ? pk.CW : W) + TW - 1) / TW, tiles_y = ((PACKED ? pk.CH : H) + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
-    const int ntiles = d.N * tiles_img;
+    const int ntiles = PACKED ? tiles_img : d.N * tiles_img;
+    // inside(Y, X): is tile pixel (Y, X) a real pixel (of any image, when packed)?
+    auto inside = [&](int y, int x) {
+        int pn, py, px;
+        return PACKED ? pk_locate(pk, y, x, pn, py, px) : (y < H && x < W);
+    };
 
     // ---- prefetch registers: raw dy / z_out (haloed) and x (interior) of the NEXT tile ------------
     // Loaded through per-image buffer descriptors: one 32-bit byte offset per slot, and a slot
@@ -169,22 +175,32 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     auto issue = [&](int t) {
         const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(d.dy) + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(d.z) + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
+        // packed: descriptors over the whole tensors, the image index is part of the offset
+        const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : zbytes;
+        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
+        const size_t zbase = PACKED ? (size_t)0 : (size_t)n * d.z_img_stride;
+        const size_t xbase = PACKED ? (size_t)0 : (size_t)n * d.x_img_stride;
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy) + zbase, 0, zrange, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z) + zbase, 0, zrange, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + xbase, 0, xrange, 0x00020000);
         int hp = tid / G::C4O;
         int hy = hp / G::HW_, hx = hp - hy * G::HW_;
         okmask = 0;
 #pragma unroll
         for (int i = 0; i < G::NDZ; ++i) {
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const unsigned off = ok ? (unsigned)((y * W + x) * COUT + och4 * 4) * 4u : zbytes;
+            bool ok;
+            unsigned off;
+            if constexpr (PACKED) {
+                int pn, py, px;
+                ok = hp < G::HP && pk_locate(pk, y, x, pn, py, px);
+                off = ok ? (unsigned)(pn * d.z_img_stride + (py * W + px) * COUT + och4 * 4) * 4u : zrange;
+            } else {
+                ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                off = ok ? (unsigned)((y * W + x) * COUT + och4 * 4) * 4u : zbytes;
+            }
             okmask |= ok ? (1u << i) : 0u;
             const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, off, 0, 0);
             pdy[i] = *reinterpret_cast<const float4*>(&vdy);
@@ -195,22 +211,33 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             }
             hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
             if (hx >= G::HW_) { hx -= G::HW_; ++hy; }
+            // packed: finish one slot's address arithmetic before the next one starts (otherwise
+            // all 16 canvas -> image mappings are computed up front and spill)
+            if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < G::NX; ++i) {
             const int ip = (tid + BWD_THREADS * i) / G::C4I;
             const int y = y0 + ip / TW, x = x0 + ip % TW;
-            const unsigned off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+            unsigned off;
+            if constexpr (PACKED) {
+                int pn, py, px;
+                off = pk_locate(pk, y, x, pn, py, px)
+                          ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * 4u : xrange;
+            } else {
+                off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+            }
             const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
             px[i] = *reinterpret_cast<const float4*>(&vx);
+            if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     int t = blockIdx.x;
     if (t < ntiles) issue(t);
     for (; t < ntiles; t += gridDim.x) {
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
 
         // ---- stage: dz (BN backward of this unit's own BN) and a = T(x) -> LDS ------------------
         {
@@ -314,7 +341,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ip = mt * 16 + 4 * g + r;
-                    const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+                    const bool in = inside(y0 + ip / TW, x0 + ip % TW);
 #pragma unroll
                     for (int nt = 0; nt < G::NTO; ++nt)
                         s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
             }
 #pragma unroll
             for (int r = 0; r < G::PPT; ++r) {
-                const bool in = (y0 + vr0 + r) < H && (x0 + vtx) < W;
+                const bool in = inside(y0 + vr0 + r, x0 + vtx);
                 if (!in) dp[r] = make_float4(0, 0, 0, 0);
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
                 *reinterpret_cast<float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4) = dp[r];
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
                         const int ip = (wid * G::MPW + mi) * 16 + 4 * g + r;
                         float* ap = s_a + ip * G::LSI + c;
                         const float xr = *ap;
-                        const bool in = (y0 + ip / TW) < H && (x0 + ip % TW) < W;
+                        const bool in = inside(y0 + ip / TW, x0 + ip % TW);
                         const float v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? da[mi][nt][r] : 0.0f;   // ReLU mask
                         t0 += (double)v;
                         t1 += (double)(v * (bn_center(xr, cm, cl) * ci));
@@ -486,14 +513,22 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
         if (d.dx && !(abl & 16)) {
             const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
             const int ich4 = tid % G::C4I;
-            const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(d.dx + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+            const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
+            const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(
+                d.dx + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
             unsigned off[G::NX];
             u32x4 old[G::NX];
 #pragma unroll
             for (int i = 0; i < G::NX; ++i) {
                 const int ip = (tid + BWD_THREADS * i) / G::C4I;
                 const int y = y0 + ip / TW, x = x0 + ip % TW;
-                off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+                if constexpr (PACKED) {
+                    int pn, py, px;
+                    off[i] = pk_locate(pk, y, x, pn, py, px)
+                                 ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * 4u : xrange;
+                } else {
+                    off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+                }
                 if (d.accumulate_dx) old[i] = __builtin_amdgcn_raw_buffer_load_b128(r_dx, off[i], 0, 0);
             }
 #pragma unroll
@@ -566,21 +601,25 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d) {
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
 }
 
-template <int CIN, int COUT, int TH, int TW>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false>
 int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     using G = BwdGeom<CIN, COUT, TH, TW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
-    const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
+    PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
+    pk.on = PACKED ? 1 : 0;
+    if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
+    const int tiles = PACKED ? ((pk.CW + TW - 1) / TW) * ((pk.CH + TH - 1) / TH)
+                             : d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
-                       stream, *d);
+    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
+                       stream, *d, pk);
     return hip_status();
 }
 
@@ -960,7 +999,10 @@ static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
 }
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
     const int th = dp_bwd_big_tile(H, W, cin, cout) ? 16 : 8, tw = th * 2;
-    const long long tiles = (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
+    const PackGeom pk = dp_pack_geom(N, H, W);       // small maps: one tile grid over the packed canvas
+    const long long tiles = dp_use_pack_bwd(N, H, W, cin, cout)
+                                ? (long long)((pk.CW + tw - 1) / tw) * ((pk.CH + th - 1) / th)
+                                  : (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
     return (int)(tiles < DP_BWD_MAX_BLOCKS ? tiles : DP_BWD_MAX_BLOCKS);
 }
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W) {
@@ -977,6 +1019,8 @@ extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
     if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))
         return launch_dp_bwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
+    if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout))             // 20x20 / 10x10 levels: packed canvas
+        return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

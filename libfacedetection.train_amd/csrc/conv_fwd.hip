@@ -199,8 +199,8 @@ struct DpGeom {
     static_assert(256 % C4I == 0, "load mapping");
 };
 
-template <int CIN, int COUT, int TH, int TW>
-__global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
+template <int CIN, int COUT, int TH, int TW, bool PACKED>
+__global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const PackGeom pk) {
     using G = DpGeom<CIN, COUT, TH, TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* buf = reinterpret_cast<float*>(smem_raw);
@@ -235,9 +235,10 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     const int lch4 = tid % G::C4I;  // input channel quad of this thread in the load phase
     __syncthreads();
 
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    // per-image tiling, or (PACKED) one tile grid over the packed canvas of all images
+    const int tiles_x = ((PACKED ? pk.CW : W) + TW - 1) / TW, tiles_y = ((PACKED ? pk.CH : H) + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
-    const int ntiles = d.N * tiles_img;
+    const int ntiles = PACKED ? tiles_img : d.N * tiles_img;
 
     // prefetch registers: this thread's slice of the NEXT tile's raw halo input, loaded through
     // a per-image buffer descriptor: one 32-bit byte offset per slot, and a slot outside the
@@ -248,17 +249,27 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     constexpr int PSTEP = 256 / G::C4I;                   // halo pixels between a thread's slots
     constexpr int HSTEP_Y = PSTEP / G::HW_, HSTEP_X = PSTEP % G::HW_;
     auto issue = [&](int t) {
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
+        // packed: one descriptor over the whole tensor, the image index is part of the offset
+        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+            const_cast<float*>(d.x) + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
         int hp = tid / G::C4I;
         int hy = hp / G::HW_, hx = hp - hy * G::HW_;
 #pragma unroll
         for (int i = 0; i < G::NLD; ++i) {
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const unsigned off = ok ? (unsigned)((y * W + x) * CIN + lch4 * 4) * 4u : xbytes;
+            bool ok;
+            unsigned off;
+            if constexpr (PACKED) {
+                int pn, py, px;
+                ok = hp < G::HP && pk_locate(pk, y, x, pn, py, px);
+                off = ok ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + lch4 * 4) * 4u : xrange;
+            } else {
+                ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                off = ok ? (unsigned)((y * W + x) * CIN + lch4 * 4) * 4u : xbytes;
+            }
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
             pre[i] = *reinterpret_cast<const float4*>(&v);
             hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
@@ -277,8 +288,8 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     if (t < ntiles) issue(t);
     for (; t < ntiles; t += gridDim.x) {
         if (prof) c0 = clock64();
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
         // ---- stage: registers -> LDS with the input transform ----------------------------------
         {
             const float4 cm = *reinterpret_cast<const float4*>(s_coef + lch4 * 4);
@@ -353,7 +364,9 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                 const int y = y0 - 1 + hy, x = x0 - 1 + hx;
                 // the depthwise conv zero-pads the POINTWISE OUTPUT: outside the image p = 0,
                 // not pw(0)+bias (SURVEY.md 7 "zero-halo trap")
-                const bool in = hp < G::HP && y >= 0 && y < H && x >= 0 && x < W;
+                int pn, py, px;
+                const bool in = hp < G::HP && (PACKED ? pk_locate(pk, y, x, pn, py, px)
+                                                     : (y >= 0 && y < H && x >= 0 && x < W));
 #pragma unroll
                 for (int nt = 0; nt < G::NT; ++nt)
                     buf[hp * G::LS + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
@@ -363,7 +376,9 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
         if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }
         // ---- dw: depthwise 3x3 from LDS, bias, store raw z, BN statistics ------------------------
         if (!(abl & 2)) {
-            const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
+            const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : zbytes;
+            const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
+                d.z + (PACKED ? (size_t)0 : (size_t)n * d.z_img_stride), 0, zrange, 0x00020000);
             const float* pbase = buf + dtx * G::LS + cq * 4;
             float4 w2[9];
 #pragma unroll
@@ -394,10 +409,13 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
                     o.z = fmaf(rowC[j].z, w2[6 + j].z, o.z); o.w = fmaf(rowC[j].w, w2[6 + j].w, o.w);
                 }
                 const int y = y0 + r0 + r, x = x0 + dtx;
-                if (y < H && x < W) {
+                int pn = 0, py = y, px = x;
+                const bool inside = PACKED ? pk_locate(pk, y, x, pn, py, px) : (y < H && x < W);
+                if (inside) {
                     if (!(abl & 4))
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z,
-                                                               (unsigned)((y * W + x) * COUT + cq * 4) * 4u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            *reinterpret_cast<const u32x4*>(&o), r_z,
+                            (unsigned)(pn * (PACKED ? d.z_img_stride : 0) + (py * W + px) * COUT + cq * 4) * 4u, 0, 0);
                     ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
                     ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
                     ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
@@ -434,12 +452,12 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d) {
     }
 }
 
-template <int CIN, int COUT, int TH, int TW>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false>
 int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
     using G = DpGeom<CIN, COUT, TH, TW>;
     static int blocks_per_cu = 0;
     if (!blocks_per_cu) {
-        const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW>);
+        const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW, PACKED>);
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
@@ -449,10 +467,14 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
             if (atoi(e) >= 1 && atoi(e) <= blocks_per_cu) blocks_per_cu = atoi(e);
     }
     // persistent grid: exactly the resident workgroups, so every one pipelines many tiles
-    const int tiles = d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
+    PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
+    pk.on = PACKED ? 1 : 0;
+    if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
+    const int tiles = PACKED ? ((pk.CW + TW - 1) / TW) * ((pk.CH + TH - 1) / TH)
+                             : d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
     const int resident = 256 * blocks_per_cu;
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW>), dim3(grid), dim3(256), G::SMEM, stream, *d);
+    hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW, PACKED>), dim3(grid), dim3(256), G::SMEM, stream, *d, pk);
     return hip_status();
 }
 
@@ -559,6 +581,8 @@ extern "C" int yunet_dp_fwd(const YunetDP* d, void* stream) {
     if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
     if (d->cin == 16 && d->cout == 16 && d->W >= 64 && d->H >= 32)
         return launch_dp_fwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
+    if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout))                 // 20x20 / 10x10 levels: packed canvas
+        return d->cout == 64 ? launch_dp_fwd<64, 64, 8, 16, true>(d, s) : launch_dp_fwd<64, 16, 8, 16, true>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

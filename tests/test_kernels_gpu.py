@@ -49,7 +49,8 @@ def mk_unit(cin, cout, g):
     return w_pw, b_pw, w_dw, b_dw
 
 
-SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5)]
+SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5),
+          (5, 10, 10), (4, 20, 20), (19, 10, 10), (6, 7, 13)]     # N >= 4 and H, W <= 20: packed-canvas tiling
 CHANNELS = [(16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64), (64, 16)]
 
 
