@@ -115,7 +115,7 @@ static inline bool dp_use_pack(int N, int H, int W, int cin, int cout) {
 // the packed 64->64 one does not yet (its canvas mapping pushes the kernel into scratch), so the
 // latter keeps the per-image tiling
 static inline bool dp_use_pack_bwd(int N, int H, int W, int cin, int cout) {
-    return cout == 16 && dp_use_pack(N, H, W, cin, cout);
+    return dp_use_pack(N, H, W, cin, cout);
 }
 static inline bool dp_pack_fits(const PackGeom& g, long long x_img_stride, long long z_img_stride) {
     const long long lim = 1ll << 30;           // floats

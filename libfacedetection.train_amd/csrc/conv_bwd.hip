@@ -41,7 +41,7 @@ struct BwdGeom {
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
     static constexpr int WORK_F = OFF_PB + IP * LSO;
-    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST + 4 * CIN;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums
+    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST + 4 * CIN + IP / 4;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums | validity bytes
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
     static constexpr size_t WORK = (size_t)WORK_F * 4;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
     float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM)
     double* s_bst = reinterpret_cast<double*>(s_w1t + CIN * G::WST);   // [2][CIN] producer's BN-backward sums
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_bst + 2 * CIN);   // [IP] packed mode: pixel is real
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -156,10 +157,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     const int tiles_x = ((PACKED ? pk.CW : W) + TW - 1) / TW, tiles_y = ((PACKED ? pk.CH : H) + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
     const int ntiles = PACKED ? tiles_img : d.N * tiles_img;
-    // inside(Y, X): is tile pixel (Y, X) a real pixel (of any image, when packed)?
-    auto inside = [&](int y, int x) {
-        int pn, py, px;
-        return PACKED ? pk_locate(pk, y, x, pn, py, px) : (y < H && x < W);
+    // inside(ip, Y, X): is interior tile pixel ip = (Y, X) a real pixel?  Packed tiles look it up in
+    // a per-tile byte map written during the stage (one canvas -> image mapping per pixel and tile
+    // instead of one per use).
+    auto inside = [&](int ip, int y, int x) {
+        if constexpr (PACKED) return s_in[ip] != 0;
+        else return y < H && x < W;
     };
 
     // ---- prefetch registers: raw dy / z_out (haloed) and x (interior) of the NEXT tile ------------
@@ -271,6 +274,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                     *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
                 }
             }
+            if constexpr (PACKED) {
+                for (int ip = tid; ip < G::IP; ip += BWD_THREADS) {
+                    int pn, py, px;
+                    s_in[ip] = pk_locate(pk, y0 + ip / TW, x0 + ip % TW, pn, py, px) ? 1 : 0;
+                }
+            }
             // the interior input tile goes to LDS RAW; the input transform (BN+ReLU of the
             // producer) is applied where MFMA operands are read, so the raw values stay available
             // for the ReLU mask and the BN-backward sums of the producer
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ip = mt * 16 + 4 * g + r;
-                    const bool in = inside(y0 + ip / TW, x0 + ip % TW);
+                    const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
 #pragma unroll
                     for (int nt = 0; nt < G::NTO; ++nt)
                         s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
 #pragma unroll
             for (int r = 0; r < G::PPT; ++r) {
-                const bool in = inside(y0 + vr0 + r, x0 + vtx);
+                const bool in = inside((vr0 + r) * TW + vtx, y0 + vr0 + r, x0 + vtx);
                 if (!in) dp[r] = make_float4(0, 0, 0, 0);
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
                 *reinterpret_cast<float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4) = dp[r];
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                         const int ip = (wid * G::MPW + mi) * 16 + 4 * g + r;
                         float* ap = s_a + ip * G::LSI + c;
                         const float xr = *ap;
-                        const bool in = inside(y0 + ip / TW, x0 + ip % TW);
+                        const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
                         const float v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? da[mi][nt][r] : 0.0f;   // ReLU mask
                         t0 += (double)v;
                         t1 += (double)(v * (bn_center(xr, cm, cl) * ci));
@@ -1020,7 +1029,7 @@ extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
     if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))
         return launch_dp_bwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
     if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout))             // 20x20 / 10x10 levels: packed canvas
-        return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
+        return d->cout == 64 ? launch_dp_bwd<64, 64, 8, 16, true>(d, s) : launch_dp_bwd<64, 16, 8, 16, true>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)
