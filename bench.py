@@ -117,10 +117,16 @@ def op_name(op, L):
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
              L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',
              L.OP_REDUCE_BATCH: 'reduce_partials_batch_kernel', L.OP_BN_BATCH: 'bn_batch_kernel'}
-    if op.opcode == L.OP_DP_FWD:
-        return f'dp_fwd_kernel<{op.dp.cin},{op.dp.cout},8,16>'
-    if op.opcode == L.OP_DP_BWD:
-        return f'dp_bwd_kernel<{op.dp.cin},{op.dp.cout},8,16>'
+    if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
+        # the template instance the C dispatcher picks (csrc/conv_fwd.hip / conv_bwd.hip / common.h):
+        # 16x32 tiles for 16->16 on big maps, packed-canvas tiling for 64->{64,16} on maps <= 20x20
+        d = op.dp
+        big = d.cin == 16 and d.cout == 16 and d.W >= 64 and d.H >= 32
+        packed = (d.cin == 64 and d.cout in (64, 16) and d.H <= 20 and d.W <= 20 and d.N >= 4
+                  and not os.environ.get('YUNET_NO_PACK'))
+        kind = 'fwd' if op.opcode == L.OP_DP_FWD else 'bwd'
+        return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"
+                f"{'true' if packed and not big else 'false'}>")
     return names.get(op.opcode, f'op{op.opcode}')
 
 
