@@ -45,8 +45,33 @@ def parse():
     p.add_argument('--kind', default=KIND, choices=['n', 's'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    p.add_argument('--gpu-eager-only', action='store_true', help=argparse.SUPPRESS)
+    p.add_argument('--no-gpu-eager', action='store_true',
+                   help='skip the un-accelerated-GPU row (the oracle\'s eager torch ops on cuda:0)')
     p.add_argument('--no-roofline', action='store_true')
     return p.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one
+    rank per GPU over RCCL (what tools/dist_train.sh:11-21 does for the reference)."""
+    import socket
+    import subprocess
+    backend = os.environ.get('YUNET_DIST_BACKEND', 'nccl')
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and have < a.gpus:
+        raise SystemExit(f'--gpus {a.gpus}: only {have} GPU(s) visible; RCCL needs one device per rank '
+                         '(YUNET_DIST_BACKEND=gloo lets ranks share a GPU for debugging)')
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 # ----------------------------------------------------------------- algorithmic byte model
@@ -190,8 +215,24 @@ def effective_cores():
     return cores
 
 
-def cpu_baseline_worker(kind, size, seed=1234, budget_s=12.0):
-    """The CPU oracle's full training step on a bounded sample of the same workload."""
+def ref_vs_port():
+    """Measured ratio reference-under-stub / port on the build box (profiles/r*_cpu_ref_vs_port.json,
+    written by tools/cpu_ref_vs_port.py where /root/reference exists); None if never measured."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_ref_vs_port.json')))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))
+    except Exception:
+        return None
+
+
+def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
+    """The oracle's full training step (a port of the reference step: eager torch ops + a Python
+    loop over images for SimOTA) on a bounded sample of the same workload.  device='cpu' is the
+    cpu_baseline; device='cuda' is the 'un-accelerated GPU' row -- the same eager ops through
+    stock PyTorch-ROCm (MIOpen / rocBLAS) on the MI355X."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import yunet_oracle as O
     import yunet_amd.synthetic as S
@@ -200,36 +241,66 @@ def cpu_baseline_worker(kind, size, seed=1234, budget_s=12.0):
     arch = O.yunet_arch(kind)
     sd = O.init_state(arch, seed=0)
     opt = O.SGD(lr=1e-5)
-    bs = 16
+    bs = 32
     b = S.make_batch(bs, size, size, seed)
-    O.train_step(b, sd, arch, opt)          # warm-up
+    sync = (lambda: None)
+    if device != 'cpu':
+        dev = torch.device(device)
+        sd = {k: v.to(dev) for k, v in sd.items()}
+        b = dict(b, img=b['img'].to(dev), gt_bboxes=[t.to(dev) for t in b['gt_bboxes']],
+                 gt_labels=[t.to(dev) for t in b['gt_labels']],
+                 gt_keypointss=[t.to(dev) for t in b['gt_keypointss']])
+        sync = torch.cuda.synchronize
+    O.train_step(b, sd, arch, opt)          # warm-up (MIOpen kernel selection on the GPU)
+    sync()
     t0 = time.time()
     iters = 0
     while iters < 2 or (time.time() - t0 < budget_s and iters < 50):
         O.train_step(b, sd, arch, opt)
         iters += 1
+    sync()
     dt = time.time() - t0
-    return dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
-                sample=f'oracle/yunet_oracle.py train_step (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} '
-                       f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch CPU fp32, '
-                       f'{cores} threads')
+    what = (f'oracle/yunet_oracle.py train_step (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} '
+            f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch fp32')
+    if device != 'cpu':
+        return dict(value=round(bs * iters / dt, 2), unit='images/sec', kind='port',
+                    sample=what + ', eager PyTorch-ROCm ops on cuda:0 (un-accelerated GPU row)')
+    res = dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
+               sample=what + f', {cores} threads')
+    rp = ref_vs_port()
+    if rp:
+        res['reference_over_port'] = rp.get('ratio')
+        res['sample'] += (f"; on the build box ({rp.get('cores')} cores) the reference's own files under the "
+                          f"mmcv stub ran {rp.get('reference_img_s')} img/s vs this port {rp.get('port_img_s')} "
+                          f"img/s (ratio {rp.get('ratio')}, tools/cpu_ref_vs_port.py)")
+    return res
+
+
+def _child(flag, kind, size, timeout, env_extra):
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), flag, '--kind', kind,
+                              '--size', str(size)], capture_output=True, text=True, timeout=timeout,
+                             env=dict(os.environ, **env_extra))
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(value=None, unit='images/sec', kind='port',
+                    sample='worker produced no result: ' + out.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='images/sec', kind='port',
+                    sample=f'worker exceeded its {timeout} s bound')
 
 
 def cpu_baseline(kind, size):
     """Run the worker in a child process with a hard wall-clock bound."""
-    import subprocess
-    try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only',
-                              '--kind', kind, '--size', str(size)], capture_output=True,
-                             text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
-        for line in reversed(out.stdout.strip().splitlines()):
-            if line.startswith('{'):
-                return json.loads(line)
-        return dict(value=None, unit='images/sec', cores=effective_cores(), kind='port',
-                    sample='cpu baseline worker produced no result: ' + out.stderr[-200:])
-    except subprocess.TimeoutExpired:
-        return dict(value=None, unit='images/sec', cores=effective_cores(), kind='port',
-                    sample='cpu baseline worker exceeded its 240 s bound')
+    r = _child('--cpu-baseline-only', kind, size, 300, dict(HIP_VISIBLE_DEVICES=''))
+    r.setdefault('cores', effective_cores())
+    return r
+
+
+def gpu_eager(kind, size):
+    return _child('--gpu-eager-only', kind, size, 240, {})
 
 
 def main():
@@ -237,12 +308,14 @@ def main():
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline_worker(a.kind, a.size)))
         return
+    if a.gpu_eager_only:
+        print(json.dumps(cpu_baseline_worker(a.kind, a.size, budget_s=10.0, device='cuda')))
+        return
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 '
-                         '--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...')
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -292,10 +365,13 @@ def main():
         dist.barrier(**bar)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [float(v.item()) for v in every]
+        dt = max(per_rank)                              # the job is as fast as its slowest rank
     last_loss = float(out['log_vars']['loss'])
 
     res = None
@@ -312,6 +388,11 @@ def main():
                                    'synthetic WIDER-Face-shaped batches, fp32',
                        'parallelism': f'dp{world}', 'global_batch': world * a.batch},
             'final_loss': round(last_loss, 4),
+            'per_rank_images_per_sec': [round(a.batch * a.steps / t, 1) for t in per_rank],
+            'dist': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world,
+                     'collectives_per_step': 0 if world == 1 else 3,
+                     'note': 'num_pos (4 B) | gradient bucket A on a side stream under the backward '
+                             'kernels of the early stages | bucket B + the 5 logged scalars'},
         }
     if rank == 0 and world == 1 and not a.no_roofline:
         agg = profile_ops(model.engine)
@@ -340,6 +421,10 @@ def main():
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(a.kind, a.size)
+        if not a.no_gpu_eager:
+            del model, wrapped, opt, pool          # hand the GPU to the child process
+            torch.cuda.empty_cache()
+            res['cpu_baseline']['gpu_eager'] = gpu_eager(a.kind, a.size)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

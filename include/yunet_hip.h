@@ -195,12 +195,16 @@ typedef struct YunetLossCfg {
  * losses/utils.py:29-55).  norm[0] is the (all-reduced) mean num_pos, clamped to >= 1
  * inside.  dflat [N,P,16] receives d(loss_c)/d(flat) for the loss that owns channel c,
  * each with unit upstream gradient.  partials [blocks,4] -> losses via
- * yunet_loss_finalize (losses = {cls, bbox, obj, kps}). */
+ * yunet_loss_finalize: losses[5] = {cls, bbox, obj, kps, total}, total = ((cls+bbox)+obj)+kps
+ * in fp32 -- the sum _parse_losses builds (mmdet/models/detectors/base.py:206-209).
+ * `mirror` (nullable) receives the same five floats a second time: the host keeps it behind
+ * the flat gradient buffer so that the logged scalars ride in the gradient all-reduce. */
 int yunet_loss(const float* flat, const int32_t* gt_inds, const float* max_overlaps,
                const float* gt_boxes, const float* gt_kps, const YunetLevels* lv,
                const YunetLossCfg* cfg, const float* norm, int N, int P, int Gmax,
                float* dflat, float* partials, int blocks, void* stream);
-int yunet_loss_finalize(const float* partials, int blocks, float* losses, void* stream);
+int yunet_loss_finalize(const float* partials, int blocks, float* losses, float* mirror,
+                        void* stream);
 int yunet_loss_blocks(int N, int P);
 
 /* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */

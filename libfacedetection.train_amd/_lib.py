@@ -101,7 +101,7 @@ _SIGNATURES = {
     'yunet_loss': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels), C.POINTER(YunetLossCfg),
                                                 C.c_void_p] + [C.c_int] * 3 +
                    [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),

@@ -522,14 +522,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
 }
 
 __global__ void loss_finalize_kernel(const float* __restrict__ partials, int blocks,
-                                     float* __restrict__ losses) {
+                                     float* __restrict__ losses, float* __restrict__ mirror) {
     // 4 waves, one per loss term; fp64 accumulation in a fixed order
+    __shared__ float s_l[4];
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double v = 0.0;
     for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 4 + k];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) losses[k] = (float)v;
+    if (lane == 0) s_l[k] = (float)v;
+    __syncthreads();
+    // losses[4] = the total the reference builds in _parse_losses (base.py:206-209): a python sum()
+    // over the dict in insertion order, i.e. ((cls + bbox) + obj) + kps in fp32
+    if (threadIdx.x < 5) {
+        const float tot = ((s_l[0] + s_l[1]) + s_l[2]) + s_l[3];
+        const float o = threadIdx.x < 4 ? s_l[threadIdx.x] : tot;
+        losses[threadIdx.x] = o;
+        if (mirror) mirror[threadIdx.x] = o;
+    }
 }
 
 }  // namespace
@@ -591,8 +601,9 @@ extern "C" int yunet_loss(const float* flat, const int32_t* gt_inds, const float
     return -(int)hipGetLastError();
 }
 
-extern "C" int yunet_loss_finalize(const float* partials, int blocks, float* losses, void* stream) {
+extern "C" int yunet_loss_finalize(const float* partials, int blocks, float* losses, float* mirror,
+                                   void* stream) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials,
-                       blocks, losses);
+                       blocks, losses, mirror);
     return -(int)hipGetLastError();
 }

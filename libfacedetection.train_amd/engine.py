@@ -24,6 +24,7 @@ from . import kernels as K
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+LOG_HEAD = 8          # floats in front of the flat gradient: cls, bbox, obj, kps, total, 3 spare
 
 
 # ============================================================================ parameters
@@ -133,7 +134,12 @@ class FlatParams:
         self.layout = layout
         self.device = device
         self.data = torch.zeros(layout.numel, device=device, dtype=torch.float32)
-        self.grad = torch.zeros(layout.numel, device=device, dtype=torch.float32)
+        # One allocation  [ log scalars (LOG_HEAD floats) | gradient of every parameter ]: the five
+        # logged loss values sit in front of the gradient so that they travel in the gradient
+        # all-reduce of the last bucket ("logging scalars folded into the same buffer").
+        self.grad_buf = torch.zeros(LOG_HEAD + layout.numel, device=device, dtype=torch.float32)
+        self.log_head = self.grad_buf[:LOG_HEAD]
+        self.grad = self.grad_buf[LOG_HEAD:]
         nb = len(layout.bn_names)
         self.bn_channels = []
         for name in layout.bn_names:
@@ -280,7 +286,7 @@ class Plan:
         self.img_stats = torch.empty(n, 2, **f32)
         self.scratch = torch.empty(n, self.P, 8, **f32)
         self.norm = torch.zeros(4, **f32)
-        self.losses = torch.zeros(4, **f32)
+        self.losses = torch.zeros(8, **f32)        # cls, bbox, obj, kps, total (3 spare)
         lib = L.load()
         self.loss_blocks = lib.yunet_loss_blocks(n, self.P)
         self.loss_partials = torch.empty(self.loss_blocks, 4, **f32)
@@ -308,7 +314,8 @@ class Plan:
                                   arch['loss_kps_weight'], 1e-6, 0.1, arch['kps_beta'])
         self.fwd_b.append(op)
         self.fwd_b.append(self._op(L.OP_LOSS_FINALIZE, p=[self.loss_partials.data_ptr(),
-                                                         self.losses.data_ptr()],
+                                                         self.losses.data_ptr(),
+                                                         fp.log_head.data_ptr()],
                                    i=[self.loss_blocks]))
         # BN running statistics (nn.BatchNorm2d momentum 0.1) and, in backward, d(gamma)/d(beta)
         # of ALL BatchNorm layers: one launch each, driven by a small device table
@@ -330,8 +337,11 @@ class Plan:
 
         # ---- backward: reverse of the forward nodes
         self.reduce_jobs = []   # (partials ptr, grad ptr, rows, width, accumulate) of every unit
+        marks = []              # after each backward node: (#ops, #reduce jobs)
         for node in reversed(self.bwd_nodes):
             node()
+            marks.append((len(self.bwd), len(self.reduce_jobs)))
+        kernels_bwd = list(self.bwd)
         # all weight-gradient partial reductions in ONE launch (table lives on the device)
         self.reduce_table, chunk = K.reduce_job_table(self.reduce_jobs, dev)
         self.bwd.append(self._op(L.OP_REDUCE_BATCH, p=[self.reduce_table.data_ptr()],
@@ -343,6 +353,42 @@ class Plan:
         self.c_fwd_b = self._carray(self.fwd_b)
         self.c_bwd = self._carray(self.bwd)
 
+        # ---- world > 1: the same backward in TWO segments so that the gradient all-reduce of the
+        # first bucket (head, neck and the backbone stages from the first pyramid tap on: the tail
+        # of the flat buffer, ~85 % of the parameters) runs on a side stream underneath the backward
+        # kernels of the early, high-resolution stages (stem .. model2: most of the backward time).
+        # The reference gets this overlap from the DDP reducer (mmdet/apis/train.py:156-161).
+        # A unit's weight-gradient partials and the d(gamma)/d(beta) of its BatchNorm are final once
+        # its own backward kernel has run (the BN sums come from its consumers, which ran earlier).
+        self.split_off = None
+        split_unit = f"backbone.model{min(arch['out_idx'])}.conv1"
+        if split_unit in lay.units and lay.units[split_unit]['off'] > 0:
+            split_off = lay.units[split_unit]['off']
+            gbase = fp.grad.data_ptr()
+            done = [j for j in self.reduce_jobs if j[1] - gbase >= 4 * split_off]
+            # the jobs of bucket A must be a prefix of the execution order
+            n_a = len(done)
+            if n_a and all(j[1] - gbase >= 4 * split_off for j in self.reduce_jobs[:n_a]):
+                ops_a = max(m[0] for m in marks if m[1] <= n_a)
+                tab_a, chunk_a = K.reduce_job_table(self.reduce_jobs[:n_a], dev)
+                tab_b, chunk_b = K.reduce_job_table(self.reduce_jobs[n_a:], dev)
+                rb_a = [r for r in rows_b if r[4] >= split_off]
+                rb_b = [r for r in rows_b if r[4] < split_off]
+                self.bn_table_ba = torch.tensor(rb_a, dtype=torch.int32).to(dev)
+                self.bn_table_bb = torch.tensor(rb_b, dtype=torch.int32).to(dev)
+                self.keep += [tab_a, tab_b]
+
+                def tail_ops(tab, nj, ch, bnt, nb):
+                    return [self._op(L.OP_REDUCE_BATCH, p=[tab.data_ptr()], i=[nj, ch]),
+                            self._op(L.OP_BN_BATCH, p=[bnt.data_ptr(), self.stats.data_ptr(), None, None,
+                                                       fp.grad.data_ptr()], i=[nb, 1], f=[0.0])]
+                self.bwd_a = kernels_bwd[:ops_a] + tail_ops(tab_a, n_a, chunk_a, self.bn_table_ba, len(rb_a))
+                self.bwd_b = kernels_bwd[ops_a:] + tail_ops(tab_b, len(self.reduce_jobs) - n_a, chunk_b,
+                                                            self.bn_table_bb, len(rb_b))
+                self.c_bwd_a = self._carray(self.bwd_a)
+                self.c_bwd_b = self._carray(self.bwd_b)
+                self.split_off, self.split_ops = split_off, ops_a
+
         # ---- eval(): the same conv-stack launches with BatchNorm on the running statistics
         # (op 0 fills the sums from running_mean / running_var instead of zeroing them; producers
         # do not accumulate: ConvDPUnits get out_has_bn = 0, the stem sums into a scratch block)
@@ -351,6 +397,8 @@ class Plan:
                                                     fp.running_mean.data_ptr(), fp.running_var.data_ptr(), None],
                                   i=[len(rows_f), 2], f=[0.0])]
         for op in self.fwd_a[1:]:
+            if op.opcode in (L.OP_ASSIGN, L.OP_LOSS_NORM):
+                continue          # test time: no SimOTA on stale GT, gt_inds / norm stay untouched
             cp = L.YunetOp()
             C.memmove(C.byref(cp), C.byref(op), C.sizeof(L.YunetOp))
             if cp.opcode == L.OP_DP_FWD:
@@ -543,6 +591,11 @@ class Plan:
             arr[idx].p[0] = ptr
             if which == 'fwd_a':
                 self.c_fwd_eval[idx].p[0] = ptr       # same position: op 0 is replaced, not removed
+            elif self.split_off is not None:          # the two-segment copy of the backward list
+                if idx < self.split_ops:
+                    self.c_bwd_a[idx].p[0] = ptr
+                else:
+                    self.c_bwd_b[idx - self.split_ops].p[0] = ptr
 
 
 class YuNetEngine:
@@ -557,6 +610,7 @@ class YuNetEngine:
         self.process_group = process_group
         self.plans = {}
         self.plan = None
+        self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
         self.lib = L.load()
         self._host_idx = {}
 
@@ -571,7 +625,15 @@ class YuNetEngine:
             plan.gt_kps.copy_(pk, non_blocking=True)
             plan.gt_count.copy_(gt_bboxes.counts, non_blocking=True)
             return
-        counts = [int(b.shape[0]) for b in gt_bboxes]
+        cnt_t = getattr(gt_bboxes, 'counts', None)
+        if cnt_t is not None:
+            # a GTList whose padded companion does not fit this plan (other Gmax / host-resident):
+            # its counts are authoritative -- list items may be padded views with zero rows
+            counts = [int(c) for c in cnt_t.tolist()]
+            gt_bboxes = [b[:c] for b, c in zip(gt_bboxes, counts)]
+            gt_keypointss = [k[:c] for k, c in zip(gt_keypointss, counts)]
+        else:
+            counts = [int(b.shape[0]) for b in gt_bboxes]
         tot = sum(counts)
         plan.gt_count.copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=True)
         if tot == 0:
@@ -607,8 +669,13 @@ class YuNetEngine:
         assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
         n, _, h, w = img.shape
         pb = getattr(gt_bboxes, 'padded', None)
-        max_gt = int(pb.shape[1]) if pb is not None else \
-            max([int(b.shape[0]) for b in gt_bboxes] + [1])
+        cnt_t = getattr(gt_bboxes, 'counts', None)
+        if pb is not None:
+            max_gt = int(pb.shape[1])
+        elif cnt_t is not None:
+            max_gt = max(int(cnt_t.max()), 1)
+        else:
+            max_gt = max([int(b.shape[0]) for b in gt_bboxes] + [1])
         plan = self.get_plan(n, h, w, max_gt)
         self.plan = plan
         self._img = img
@@ -627,7 +694,37 @@ class YuNetEngine:
             s = [float(v) for v in grad_scales]
             vec = [s[0]] + [s[1]] * 4 + [s[2]] + [s[3]] * 10
             plan.dy_scale.copy_(torch.tensor(vec, dtype=torch.float32), non_blocking=True)
-        self._exec(plan.c_bwd, 'yunet_exec(bwd)')
+        if (self.world_size <= 1 and not self.always_bucket) or plan.split_off is None:
+            self._exec(plan.c_bwd, 'yunet_exec(bwd)')
+            self.allreduce_grads()
+            return
+        # two segments: bucket A (tail of the flat buffer) is all-reduced on the side stream
+        # while the kernels of segment B run; bucket B carries the logged scalars in its head
+        main = torch.cuda.current_stream()
+        side = self._comm_stream()
+        gb, cut = self.params.grad_buf, LOG_HEAD + plan.split_off
+        self._exec(plan.c_bwd_a, 'yunet_exec(bwd_a)')
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._allreduce_mean(gb[cut:])
+        self._exec(plan.c_bwd_b, 'yunet_exec(bwd_b)')
+        self._allreduce_mean(gb[:cut])
+        main.wait_stream(side)
+
+    def _comm_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _allreduce_mean(self, t):
+        """Mean over ranks, in place, on the current stream.  RCCL averages inside the collective
+        (ncclAvg); other backends (gloo: CPU tests, several ranks sharing one GPU) sum, then scale."""
+        pg = self.process_group
+        if torch.distributed.get_backend(pg) == 'nccl':
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.AVG, group=pg)
+        else:
+            torch.distributed.all_reduce(t, group=pg)
+            t.div_(self.world_size)
 
     def reduce_num_pos(self, norm):
         """reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74, yunet_head.py:493-497):
@@ -635,12 +732,13 @@ class YuNetEngine:
         if self.world_size > 1:
             torch.distributed.all_reduce(norm[0:1], group=self.process_group)
 
-    def allreduce_grads(self, async_op=False):
-        """DDP gradient mean: ONE collective over the flat 303 KB (n) / 218 KB (s) buffer."""
+    def allreduce_grads(self):
+        """DDP gradient mean in ONE collective over [logged scalars | flat gradient]
+        (303 KB for yunet_n, 218 KB for yunet_s) -- the unsplit form of what backward() issues
+        in two buckets."""
         if self.world_size <= 1:
-            return None
-        return torch.distributed.all_reduce(self.params.grad, group=self.process_group,
-                                            async_op=async_op)
+            return
+        self._allreduce_mean(self.params.grad_buf)
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()

@@ -300,9 +300,9 @@ def loss(flat, gt_inds, ovl, gt_boxes, gt_kps, img_stats, sizes, strides, cfg, i
     L.check(lib.yunet_loss(_p(flat), _p(gt_inds), _p(ovl), _p(gt_boxes), _p(gt_kps), C.byref(lv),
                            C.byref(cfg), _p(norm), n, p, gmax, _p(dflat), _p(part), blocks,
                            _stream()), 'yunet_loss')
-    losses = torch.empty(4, device=dev, dtype=torch.float32)
-    L.check(lib.yunet_loss_finalize(_p(part), blocks, _p(losses), _stream()), 'yunet_loss_finalize')
-    return losses, dflat, norm
+    losses = torch.empty(5, device=dev, dtype=torch.float32)      # cls, bbox, obj, kps, total
+    L.check(lib.yunet_loss_finalize(_p(part), blocks, _p(losses), None, _stream()), 'yunet_loss_finalize')
+    return losses[:4], dflat, norm
 
 
 def sgd_step(params, grads, buf, lr_dev, momentum, weight_decay, grad_scale=1.0, first=False):

@@ -25,12 +25,19 @@ class FusedSGD:
         eng = self.model.engine
         if eng is None:
             raise RuntimeError('FusedSGD.step() before the first forward_train: no gradients yet')
-        if self._buf is None or self._buf.device != eng.device or \
-                self._buf.numel() != eng.params.data.numel():
+        n = eng.params.data.numel()
+        if self._buf is not None and self._buf.numel() == n and self._buf.device != eng.device:
+            # a momentum buffer restored from a checkpoint (map_location='cpu') or left behind by
+            # model.to(other device): move it, keep the step count -- do NOT restart the momentum
+            self._buf = self._buf.to(eng.device, torch.float32).contiguous()
+            self._lr_dev, self._lr_val = None, None
+        if self._buf is None or self._buf.numel() != n:
             self._buf = torch.zeros_like(eng.params.data)
+            self._lr_dev, self._lr_val = None, None
+            self._steps = 0
+        if self._lr_dev is None or self._lr_dev.device != eng.device:
             self._lr_dev = torch.zeros(1, device=eng.device)
             self._lr_val = None
-            self._steps = 0
         return eng
 
     def zero_grad(self, set_to_none=False):
@@ -54,12 +61,44 @@ class FusedSGD:
                     steps=self._steps)
 
     def load_state_dict(self, sd):
-        self.param_groups[0].update(sd['param_groups'][0])
+        """Own format (state_dict above) or the reference's torch.optim.SGD format
+        ({'state': {i: {'momentum_buffer': tensor}}, 'param_groups': [...]}, as stored in
+        weights/yunet_*.pth): per-parameter momentum buffers are laid out into the flat buffer in
+        model.parameters() order, which is the order torch numbers them in."""
+        import warnings
+        groups = sd.get('param_groups') or [{}]
+        self.param_groups[0].update({k: v for k, v in groups[0].items() if k != 'params'})
+        self._lr_dev, self._lr_val = None, None
         if sd.get('momentum_buffer') is not None:
-            self._buf = sd['momentum_buffer'].clone()
-            self._lr_dev = torch.zeros(1, device=self._buf.device)
-            self._lr_val = None
-        self._steps = sd.get('steps', 0)
+            self._buf = sd['momentum_buffer'].detach().clone().float().reshape(-1)
+            self._steps = int(sd.get('steps', 1))
+        elif isinstance(sd.get('state'), dict) and sd['state']:
+            params = list(self.model.parameters())
+            bufs = []
+            for i, p in enumerate(params):
+                st = sd['state'].get(i)
+                mb = None if st is None else st.get('momentum_buffer')
+                if mb is None or mb.numel() != p.numel():
+                    warnings.warn('optimizer state does not match the model: momentum restarts from zero')
+                    bufs = None
+                    break
+                bufs.append((p, mb))
+            if bufs is not None:
+                eng = self.model.engine
+                if eng is None:
+                    raise RuntimeError('load a torch.optim.SGD state after the model is on its GPU '
+                                       '(the flat layout is defined by the engine)')
+                flat = torch.zeros_like(eng.params.data)
+                base = eng.params.data.data_ptr()
+                for p, mb in bufs:
+                    off = (p.data_ptr() - base) // 4
+                    flat[off:off + p.numel()].copy_(mb.reshape(-1))
+                self._buf = flat
+                self._steps = 1
+        else:
+            warnings.warn('checkpoint carries no SGD momentum: it restarts from zero')
+            self._buf = None
+            self._steps = 0
 
 
 def build_optimizer(model, cfg):

@@ -56,14 +56,29 @@ class YuNetDistributedDataParallel(nn.Module):
         return self.module(*a, **k)
 
     def _to_device(self, data):
+        """scatter_kwargs of MMDistributedDataParallel for one device.  Per-image GT lists keep
+        their type: a `synthetic.GTList` / `pipelines.DeviceGT` carries the same GT padded to
+        [N, Gmax, ...] plus the per-image counts, and the engine stages those directly -- rebuilding
+        such a list as a plain list would drop them (and, for DeviceGT, whose items are padded
+        views, turn every all-zero padding row into a fake face)."""
         if self.device is None:
             return data
+        dev = self.device
+
+        def move(t):
+            return t if t.device == dev else t.to(dev, non_blocking=True)
+
         out = {}
         for k, v in data.items():
             if torch.is_tensor(v):
-                out[k] = v.to(self.device, non_blocking=True)
+                out[k] = move(v)
             elif isinstance(v, (list, tuple)) and v and torch.is_tensor(v[0]):
-                out[k] = [t.to(self.device, non_blocking=True) for t in v]
+                padded, counts = getattr(v, 'padded', None), getattr(v, 'counts', None)
+                moved = [move(t) for t in v]
+                if padded is not None and counts is not None:
+                    moved = type(v)(moved)            # GTList subclass: same type, same extras
+                    moved.padded, moved.counts = move(padded), move(counts)
+                out[k] = moved
             else:
                 out[k] = v
         return out

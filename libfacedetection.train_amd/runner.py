@@ -99,15 +99,19 @@ def load_checkpoint(model, path, optimizer=None, strict=True):
     ck = torch.load(path, map_location='cpu', weights_only=False)
     target = model.module if hasattr(model, 'module') else model
     target.load_state_dict(ck['state_dict'] if 'state_dict' in ck else ck, strict=strict)
-    if optimizer is not None and isinstance(ck.get('optimizer'), dict) and \
-            'momentum_buffer' in ck['optimizer']:
-        optimizer.load_state_dict(ck['optimizer'])
+    if optimizer is not None:
+        if isinstance(ck.get('optimizer'), dict):
+            optimizer.load_state_dict(ck['optimizer'])
+        else:
+            import warnings
+            warnings.warn(f'{path}: no optimizer state in the checkpoint, momentum restarts from zero')
     return ck.get('meta', {})
 
 
 def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None,
                    meta=None, max_iters=None, device='cuda', log=print):
-    """mmdet/apis/train.py:117 surface.  Returns the list of per-iteration log_vars."""
+    """mmdet/apis/train.py:117 surface.  Returns the logged history: one dict of python floats
+    per logging interval (every iteration for short runs with max_iters <= 64)."""
     rank, world = get_dist_info()
     model = model.to(device)
     model.train()
@@ -138,10 +142,13 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
             optimizer.zero_grad()
             out['loss'].backward()
             optimizer.step()
-            history.append(out['log_vars'])
             it += 1
-            if rank == 0 and it % interval == 0:
+            if it % interval == 0 or (max_iters is not None and max_iters <= 64):
+                # log_vars are lazily copied device scalars backed by a 256-row staging ring:
+                # freeze them into python floats when they are logged, never keep the lazy objects
                 lv = {k: float(v) for k, v in out['log_vars'].items()}
+                history.append(dict(lv, iter=it, epoch=epoch + 1, lr=lr))
+            if rank == 0 and it % interval == 0:
                 dt = (time.time() - t0) / interval
                 t0 = time.time()
                 log(f'Epoch [{epoch + 1}][{it}] lr: {lr:.3e}, time: {dt:.4f}, ' +

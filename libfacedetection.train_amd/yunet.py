@@ -15,17 +15,38 @@ from .builder import DETECTORS, build_backbone, build_head, build_neck
 from .engine import YuNetEngine
 
 
+class _LogRecord:
+    """The five logged scalars of ONE iteration: filled by an asynchronous device-to-host copy,
+    frozen into python floats the first time one of them is read (the pinned staging row is
+    reused 256 iterations later)."""
+
+    def __init__(self, model, row):
+        self.model, self.row, self.event, self.vals = model, row, None, None
+
+    def resolve(self):
+        if self.vals is None:
+            if self.event is None:
+                # world > 1: the averaged values arrive with the gradient all-reduce of backward.
+                # A collective issued from here would only be entered by the rank that reads the
+                # value (rank 0 logs) and hang, so refuse instead.
+                raise RuntimeError('log_vars of a distributed training step are available after '
+                                   'loss.backward() (they travel with the gradient all-reduce)')
+            self.event.synchronize()
+            self.vals = [float(v) for v in self.row[:5]]
+            self.model = self.row = None
+        return self.vals
+
+
 class LazyScalar:
     """A logged loss value that is copied to the host asynchronously and only waited for
     when somebody reads it (the reference calls .item() five times per iteration,
     base.py:210-215, stalling the stream each time)."""
 
-    def __init__(self, host_buf, index, event):
-        self._buf, self._i, self._ev = host_buf, index, event
+    def __init__(self, record, index):
+        self._rec, self._i = record, index
 
     def __float__(self):
-        self._ev.synchronize()
-        return float(self._buf[self._i])
+        return self._rec.resolve()[self._i]
 
     def item(self):
         return float(self)
@@ -52,20 +73,26 @@ class _EngineStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, losses):
+        """-> loss_cls, loss_bbox, loss_obj, loss_kps and their total (written by the finalize
+        kernel): train_step backpropagates the total directly, no tensor arithmetic in between."""
         ctx.model = model
         out = losses.detach().clone()
-        return out[0], out[1], out[2], out[3]
+        return out[0], out[1], out[2], out[3], out[4]
 
     @staticmethod
-    def backward(ctx, g0, g1, g2, g3):
+    def backward(ctx, g0, g1, g2, g3, gt):
         model = ctx.model
         eng = model.engine
-        z = eng.plan.dy_scale.new_zeros(())
-        gs = [g if g is not None else z for g in (g0, g1, g2, g3)]
-        eng.plan.dy_scale.copy_(torch.stack([gs[0]] + [gs[1]] * 4 + [gs[2]] + [gs[3]] * 10))
-        eng.backward()
+        if g0 is None and g1 is None and g2 is None and g3 is None and gt is not None:
+            # loss = total: one upstream scalar scales all 16 head channels
+            eng.plan.dy_scale.copy_(gt.expand(16))
+        else:
+            z = eng.plan.dy_scale.new_zeros(())
+            gs = [(g if g is not None else z) + (gt if gt is not None else z) for g in (g0, g1, g2, g3)]
+            eng.plan.dy_scale.copy_(torch.stack([gs[0]] + [gs[1]] * 4 + [gs[2]] + [gs[3]] * 10))
+        eng.backward()                      # kernels + (world > 1) the bucketed gradient all-reduce
         model._after_backward()
-        return torch.zeros(1, device=eng.device), None, None
+        return None, None, None
 
 
 @DETECTORS.register_module()
@@ -182,7 +209,33 @@ class YuNet(nn.Module):
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._log_host = torch.zeros(256, 8, dtype=torch.float32).pin_memory()
         self._log_iter = 0
+        self._log_pending = None
         return eng
+
+    # ------------------------------------------------------------------ logged scalars
+    def _log_copy(self, rec, src):
+        """src[0:5] (device) -> the record's pinned row, on a side stream; the main stream
+        (the backward / optimizer kernels that follow) never waits for it."""
+        side = getattr(self, '_log_stream', None)
+        if side is None:
+            side = self._log_stream = torch.cuda.Stream(device=src.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rec.row[:5].copy_(src[:5], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        rec.event = ev
+        self._log_last_event = ev         # the next step's loss kernels overwrite src: see forward_train
+
+    def _log_fetch_now(self, rec):
+        eng = self.engine
+        vec = eng.plan.losses[:5].clone()
+        if eng.world_size > 1:
+            eng._allreduce_mean(vec)
+        self._log_copy(rec, vec)
+        vec.record_stream(self._log_stream)
+        if self._log_pending is rec:
+            self._log_pending = None
 
     def _ensure_engine(self, device):
         if not self._bound() or self.engine.device != device:
@@ -191,9 +244,11 @@ class YuNet(nn.Module):
 
     def _after_backward(self):
         eng = self.engine
-        if eng.world_size > 1:
-            eng.allreduce_grads()
-            eng.params.grad.div_(eng.world_size)
+        rec = self._log_pending
+        if rec is not None and eng.world_size > 1:
+            # the world-averaged logged scalars arrived in the head of the gradient buffer
+            self._log_pending = None
+            self._log_copy(rec, eng.params.log_head)
         w = self.backbone.model0.conv1.weight
         if w.grad is None or w.grad.data_ptr() != eng.params.view(
                 'backbone.model0.conv1.weight', of=eng.params.grad).data_ptr():
@@ -212,9 +267,17 @@ class YuNet(nn.Module):
         if not self.training:
             raise RuntimeError('forward_train requires model.train() (batch-statistics BatchNorm)')
         eng = self._ensure_engine(img.device)
+        ev = getattr(self, '_log_last_event', None)
+        if ev is not None:
+            # the previous step's logged scalars are copied to the host on a side stream from buffers
+            # this step overwrites (a 20-byte copy issued milliseconds ago: never an actual wait)
+            torch.cuda.current_stream().wait_event(ev)
+            self._log_last_event = None
         losses = eng.forward(img.float().contiguous(), gt_bboxes, gt_keypointss)
         l = _EngineStep.apply(self._anchor, self, losses)
-        return dict(loss_cls=l[0], loss_bbox=l[1], loss_obj=l[2], loss_kps=l[3])
+        out = dict(loss_cls=l[0], loss_bbox=l[1], loss_obj=l[2], loss_kps=l[3])
+        self._last = (out, l[4])          # lets train_step use the kernel's total and log record
+        return out
 
     def _parse_losses(self, losses):
         """base.py:184-217: total = sum of the entries whose key contains 'loss'; log_vars are
@@ -231,30 +294,51 @@ class YuNet(nn.Module):
             vals = vec.cpu().tolist()
             out = OrderedDict(zip(list(log_vars) + ['loss'], vals))
             return loss, out
-        row = host[self._log_iter % host.shape[0]]     # ring: values stay valid for 256 iters
+        # generic dict (not produced by forward_train just now): world-average on a side stream
+        rec = _LogRecord(self, host[self._log_iter % host.shape[0]])
         self._log_iter += 1
-        # the world average of the logged scalars and their copy to the host run on a side
-        # stream: the backward pass that follows on the main stream never waits for them
-        side = getattr(self, '_log_stream', None)
-        if side is None:
-            side = self._log_stream = torch.cuda.Stream(device=vec.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            if dist_on:
-                vec = vec / torch.distributed.get_world_size()
+        if dist_on:
+            side = getattr(self, '_log_stream', None)
+            if side is None:
+                side = self._log_stream = torch.cuda.Stream(device=vec.device)
+            side.wait_stream(torch.cuda.current_stream())
+            vec.record_stream(side)
+            with torch.cuda.stream(side):
+                vec.div_(torch.distributed.get_world_size())
                 torch.distributed.all_reduce(vec)
-            row[:vec.numel()].copy_(vec, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        vec.record_stream(side)
-        out = OrderedDict((k, LazyScalar(row, i, ev))
-                          for i, k in enumerate(list(log_vars) + ['loss']))
+        self._log_copy(rec, vec)
+        vec.record_stream(self._log_stream)
+        out = OrderedDict((k, LazyScalar(rec, i)) for i, k in enumerate(list(log_vars) + ['loss']))
         return loss, out
+
+    def _parse_engine_losses(self, total):
+        """_parse_losses for the dict forward_train just returned: the finalize kernel already
+        wrote ((cls + bbox) + obj) + kps next to the four losses, so `loss` is that scalar (one
+        autograd edge into the fused step) and log_vars are five lazily copied floats.  World
+        size 1: copied to the host right away on a side stream.  World > 1: they sit in the head
+        of the gradient buffer and come back averaged with the gradient all-reduce that backward
+        issues (base.py:210-215 all-reduces each of them separately)."""
+        eng = self.engine
+        rec = _LogRecord(self, self._log_host[self._log_iter % self._log_host.shape[0]])
+        self._log_iter += 1
+        if eng.world_size > 1 and torch.is_grad_enabled() and total.requires_grad:
+            self._log_pending = rec
+        elif eng.world_size > 1:
+            self._log_fetch_now(rec)      # val_step / no_grad: every rank is here, no backward follows
+        else:
+            self._log_copy(rec, eng.plan.losses)
+        keys = ['loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps', 'loss']
+        return total, OrderedDict((k, LazyScalar(rec, i)) for i, k in enumerate(keys))
 
     def train_step(self, data, optimizer):
         """base.py:219-252."""
         losses = self(**data)
-        loss, log_vars = self._parse_losses(losses)
+        last = getattr(self, '_last', None)
+        self._last = None
+        if last is not None and last[0] is losses and self.engine is not None:
+            loss, log_vars = self._parse_engine_losses(last[1])
+        else:
+            loss, log_vars = self._parse_losses(losses)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     val_step = train_step

@@ -19,14 +19,16 @@ from .yunet_layer import ConvDPUnit, yunet_init_weights
 def pad_gt(gt_bboxes, gt_kpss, device):
     """ragged lists -> padded [N,Gmax,4], [N,Gmax,5,3], counts [N] int32 (on `device`)."""
     n = len(gt_bboxes)
-    counts = [int(b.shape[0]) for b in gt_bboxes]
+    cnt_t = getattr(gt_bboxes, 'counts', None)       # GTList: items may be padded views
+    counts = [int(c) for c in cnt_t.tolist()] if cnt_t is not None else \
+        [int(b.shape[0]) for b in gt_bboxes]
     gmax = max(counts + [1])
     gb = torch.zeros(n, gmax, 4, device=device)
     gk = torch.zeros(n, gmax, 5, 3, device=device)
     for i, c in enumerate(counts):
         if c:
-            gb[i, :c] = gt_bboxes[i].to(device, torch.float32)
-            gk[i, :c] = gt_kpss[i].to(device, torch.float32)
+            gb[i, :c] = gt_bboxes[i][:c].to(device, torch.float32)
+            gk[i, :c] = gt_kpss[i][:c].to(device, torch.float32)
     return gb, gk, torch.tensor(counts, dtype=torch.int32, device=device)
 
 

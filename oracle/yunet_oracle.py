@@ -280,13 +280,14 @@ def simota_assign(scores, offset_priors, decoded, gt_bboxes, gt_labels, center_r
     Returns gt_inds [P] int64 (1-based, 0 = background), labels [P] (-1 bg),
     max_overlaps [P] fp32 (-1e5 bg)."""
     P, G = decoded.shape[0], gt_bboxes.shape[0]
-    gt_inds = torch.zeros(P, dtype=torch.int64)
-    labels = torch.full((P,), -1, dtype=torch.int64)
+    dev = decoded.device          # cpu in every parity test; cuda only for bench.py's eager-GPU row
+    gt_inds = torch.zeros(P, dtype=torch.int64, device=dev)
+    labels = torch.full((P,), -1, dtype=torch.int64, device=dev)
     # --- region tests (:186-228), strict '>'
     cx, cy = offset_priors[:, 0:1], offset_priors[:, 1:2]
     sx, sy = offset_priors[:, 2:3], offset_priors[:, 3:4]
     if G == 0:
-        return gt_inds, labels, torch.zeros(P)
+        return gt_inds, labels, torch.zeros(P, device=dev)
     l_, t_ = cx - gt_bboxes[:, 0], cy - gt_bboxes[:, 1]
     r_, b_ = gt_bboxes[:, 2] - cx, gt_bboxes[:, 3] - cy
     in_gt = torch.stack([l_, t_, r_, b_], 1).min(1).values > 0
@@ -301,7 +302,7 @@ def simota_assign(scores, offset_priors, decoded, gt_bboxes, gt_labels, center_r
     in_both = in_gt[valid] & in_ct[valid]
     V = int(valid.sum())
     if V == 0:
-        return gt_inds, labels, torch.zeros(P)
+        return gt_inds, labels, torch.zeros(P, device=dev)
     # --- costs (:151-169)
     ious = pairwise_iou(decoded[valid], gt_bboxes)
     iou_cost = -torch.log(ious + eps)
@@ -314,7 +315,7 @@ def simota_assign(scores, offset_priors, decoded, gt_bboxes, gt_labels, center_r
     topk_ious = torch.sort(ious, dim=0, descending=True, stable=True).values[:K]
     dynamic_ks = torch.clamp(topk_ious.sum(0).int(), min=1)
     order = torch.sort(cost, dim=0, stable=True).indices      # ascending, ties -> low index
-    matching = torch.zeros(V, G, dtype=torch.uint8)
+    matching = torch.zeros(V, G, dtype=torch.uint8, device=dev)
     for g in range(G):
         matching[order[:int(dynamic_ks[g]), g], g] = 1
     # --- conflicts (:244-249)
@@ -330,7 +331,7 @@ def simota_assign(scores, offset_priors, decoded, gt_bboxes, gt_labels, center_r
     fg_idx = valid_idx[fg]
     gt_inds[fg_idx] = matched_gt + 1
     labels[fg_idx] = gt_labels[matched_gt].long()
-    max_overlaps = torch.full((P,), -INF_COST, dtype=torch.float32)
+    max_overlaps = torch.full((P,), -INF_COST, dtype=torch.float32, device=dev)
     max_overlaps[valid_idx] = 0.0
     max_overlaps[fg_idx] = matched_iou
     # the reference writes matched_pred_ious into the *foreground* rows only; valid
@@ -391,7 +392,7 @@ def loss_step(flat, gt_bboxes, gt_labels, gt_kpss, featmap_sizes, arch, world_me
     flat: [N, P, 16] fp32 (cls | bbox4 | obj | kps10), may require grad.
     Returns (losses dict, aux dict with per-image gt_inds / max_overlaps / num_pos)."""
     N, P, _ = flat.shape
-    priors = grid_priors(featmap_sizes, arch['strides'])
+    priors = grid_priors(featmap_sizes, arch['strides']).to(flat.device)
     cls, box, obj, kps = flat[..., 0], flat[..., 1:5], flat[..., 5], flat[..., 6:]
     decoded = bbox_decode(priors[None].expand(N, P, 4), box)
     offset_priors = torch.cat([priors[:, :2] + priors[:, 2:] * 0.5, priors[:, 2:]], -1)

@@ -78,3 +78,124 @@ def test_two_ranks_average_gradients_and_stay_in_sync():
     assert a['npos'] == b['npos'] and a['loss'] == pytest.approx(b['loss'])
     scale = float(a['g_mean'].abs().max())
     assert float((a['g_avg'] - a['g_mean']).abs().max()) <= 1e-4 * scale
+
+
+def _nccl_world1(port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    import yunet_amd
+    import yunet_amd.synthetic as S
+    import yunet_oracle as O
+    from yunet_amd.optim import FusedSGD
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yunet_amd.Config.fromfile(os.path.join(root, 'configs', 'yunet_n.py'))
+    res = {}
+    for mode in ('plain', 'bucketed'):
+        model = yunet_amd.build_detector(cfg.model)
+        model.load_state_dict(O.init_state(O.yunet_arch('n'), seed=3), strict=True)
+        model.to(dev).train()
+        ddp = YuNetDistributedDataParallel(model, device_ids=[0])
+        opt = FusedSGD(model, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        logs = None
+        for it in range(2):
+            batch = S.to_device(S.make_batch(8, 160, 160, S.batch_seed(0, it)), dev)
+            if mode == 'bucketed':
+                eng = model._ensure_engine(dev)
+                eng.always_bucket = True          # two backward segments + RCCL (ncclAvg) at world size 1
+                eng.world_size = 1
+            o = ddp.train_step(batch, opt)
+            if mode == 'bucketed':
+                # world size 1: the step logs from plan.losses; also route them through the gradient
+                # buffer head the way world > 1 does
+                model._log_pending = None
+            opt.zero_grad()
+            o['loss'].backward()
+            opt.step()
+            logs = {k: float(v) for k, v in o['log_vars'].items()}
+        torch.cuda.synchronize()
+        eng = model.engine
+        res[mode] = dict(grad=eng.params.grad.detach().cpu().clone(), params=eng.params.data.detach().cpu().clone(),
+                         head=eng.params.log_head.detach().cpu().clone(), logs=logs,
+                         split=eng.plan.split_off)
+    # a bare RCCL collective with the AVG operator on a slice of a larger buffer (what bucket A is)
+    buf = torch.arange(64, dtype=torch.float32, device=dev)
+    dist.all_reduce(buf[8:], op=dist.ReduceOp.AVG)
+    torch.cuda.synchronize()
+    res['avg_identity'] = bool(torch.equal(buf.cpu(), torch.arange(64, dtype=torch.float32)))
+    res['backend'] = dist.get_backend()
+    out.update(res)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_bucketed_allreduce_world1():
+    """The `nccl` (= RCCL) backend itself, on the one GPU of the test box: process-group init bound
+    to the device, ncclAvg on buffer slices, and the two-segment backward with the bucket-A
+    collective on the side stream -- bit-identical to the single-segment backward."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    p = mp.get_context('spawn').Process(target=_nccl_world1, args=(_free_port(), out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, p.exitcode
+    assert out['backend'] == 'nccl' and out['avg_identity']
+    a, b = out['plain'], out['bucketed']
+    assert b['split'] is not None and b['split'] > 0
+    assert torch.equal(a['grad'], b['grad']), 'two-segment backward differs from the single list'
+    assert torch.equal(a['params'], b['params'])
+    for k, v in a['logs'].items():
+        assert v == pytest.approx(b['logs'][k], rel=1e-6)
+    # loss_finalize mirrors cls, bbox, obj, kps, total into the head of the gradient buffer
+    assert b['head'][4] == pytest.approx(b['logs']['loss'], rel=1e-6)
+
+
+def test_two_gpus_rccl_if_available():
+    """Runs only where the box has >= 2 GPUs: bench.py --gpus 2 self-launches over RCCL."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (the round-end scaling run covers N = 2, 4, 8)')
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5',
+                        '--warmup', '2', '--batch', '64'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 2 and res['dist']['backend'] == 'nccl' and len(res['per_rank_images_per_sec']) == 2
+
+
+def test_ddp_through_device_pipeline_keeps_gt_counts():
+    """the DDP scatter used to rebuild GT lists as plain lists, so a DeviceGT's padded
+    zero rows became fake faces.  Train one step through pipelines.DevicePipeline behind the DDP
+    wrapper and check the engine staged the real per-image counts."""
+    import yunet_amd
+    import yunet_amd.runner as R
+    from yunet_amd.optim import FusedSGD
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yunet_amd.Config.fromfile(os.path.join(root, 'configs', 'yunet_s.py'))
+    dev = torch.device('cuda', 0)
+    model = yunet_amd.build_detector(cfg.model).to(dev).train()
+    ddp = YuNetDistributedDataParallel(model, device_ids=[0])
+    pipe = [dict(type='LoadImageFromFile', to_float32=True),
+            dict(type='LoadAnnotations', with_bbox=True, with_keypoints=True),
+            dict(type='RandomSquareCrop', crop_choice=[0.5, 0.7, 0.9, 1.1, 1.3, 1.5]),
+            dict(type='Resize', img_scale=(160, 160), keep_ratio=False),
+            dict(type='RandomFlip', flip_ratio=0.5),
+            dict(type='Normalize', mean=[0., 0., 0.], std=[1., 1., 1.], to_rgb=False),
+            dict(type='DefaultFormatBundle'), dict(type='Collect', keys=['img'])]
+    ds = R.SyntheticSourceImages(pipe, samples_per_gpu=8, pool=8)
+    batch = ds.batch(0, dev)
+    counts = batch['gt_bboxes'].counts.clone()
+    assert int(counts.max()) < batch['gt_bboxes'].padded.shape[1]       # there ARE padded rows
+    opt = FusedSGD(model, lr=1e-4)
+    o = ddp.train_step(batch, opt)
+    o['loss'].backward()
+    torch.cuda.synchronize()
+    assert torch.equal(model.engine.plan.gt_count.cpu(), counts.cpu().int())
+    assert int(model.engine.plan.gt_inds.max()) <= int(counts.max())

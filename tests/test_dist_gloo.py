@@ -30,11 +30,12 @@ def _worker(rank, world, port, out):
     # (1) gradient mean over ranks: ONE all-reduce of the flat buffer
     g_local = torch.randn(eng.layout.numel)
     eng.params.grad.copy_(g_local)
-    eng.allreduce_grads()
-    eng.params.grad.div_(world)
+    eng.params.log_head[:5] = torch.tensor([1.0, 2.0, 3.0, 4.0, 10.0]) * (rank + 1)
+    eng.allreduce_grads()            # mean over ranks of [logged scalars | flat gradient], one collective
     gathered = [torch.zeros_like(g_local) for _ in range(world)]
     dist.all_gather(gathered, g_local)
-    ok_grad = torch.allclose(eng.params.grad, sum(gathered) / world, atol=1e-6)
+    ok_grad = torch.allclose(eng.params.grad, sum(gathered) / world, atol=1e-6) and \
+        torch.allclose(eng.params.log_head[:5], torch.tensor([1.0, 2.0, 3.0, 4.0, 10.0]) * 1.5)
     # (2) reduce_mean(num_pos): every rank contributes num_pos/world, SUM
     npos = torch.tensor([17.0, 4.0])[rank]
     norm = torch.tensor([float(npos) / world, 0.0, float(npos), 0.0])
@@ -72,3 +73,37 @@ def test_world_size_2_collectives():
     assert len(out) == world
     for r in range(world):
         assert all(out[r]), (r, out[r])
+
+
+def test_ddp_scatter_keeps_padded_gt_lists():
+    """MMDistributedDataParallel.scatter stand-in: a GTList / DeviceGT must come out as the same
+    type with its padded companion and counts (the engine stages those; the list items of a
+    DeviceGT are padded views whose zero rows are NOT faces)."""
+    import yunet_amd
+    import yunet_amd.synthetic as S
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+    from yunet_amd.pipelines import DeviceGT
+    cfg = yunet_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'configs', 'yunet_s.py'))
+    w = YuNetDistributedDataParallel(yunet_amd.build_detector(cfg.model))
+    w.device = torch.device('cpu')
+    b = S.make_batch(3, 64, 64, 5)
+    out = w._to_device(b)
+    for k in ('gt_bboxes', 'gt_keypointss'):
+        assert type(out[k]) is S.GTList and out[k].padded is not None
+        assert torch.equal(out[k].padded, b[k].padded) and torch.equal(out[k].counts, b[k].counts)
+    # DeviceGT: items are [gmax, ...] views of the padded tensor
+    cnt = torch.tensor([2, 0, 5], dtype=torch.int32)
+    pb = torch.zeros(3, 64, 4)
+    for i, c in enumerate(cnt.tolist()):
+        pb[i, :c] = torch.rand(c, 4) * 50
+    dg = DeviceGT([pb[i] for i in range(3)])
+    dg.padded, dg.counts = pb, cnt
+    got = w._to_device(dict(gt_bboxes=dg))['gt_bboxes']
+    assert type(got) is DeviceGT and torch.equal(got.counts, cnt) and got.padded.shape == (3, 64, 4)
+    # pad_gt (YuNet_Head.loss API path) honours the counts of such a list
+    from yunet_amd.yunet_head import pad_gt
+    gk = DeviceGT([torch.zeros(64, 5, 3) for _ in range(3)])
+    gk.padded, gk.counts = torch.zeros(3, 64, 5, 3), cnt
+    gb2, _, c2 = pad_gt(got, gk, 'cpu')
+    assert c2.tolist() == cnt.tolist() and gb2.shape[1] == 5

@@ -51,6 +51,21 @@ def mk_unit(cin, cout, g):
 
 SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5),
           (5, 10, 10), (4, 20, 20), (19, 10, 10), (6, 7, 13)]     # N >= 4 and H, W <= 20: packed-canvas tiling
+# Shapes that select the remaining template instances / code paths of the kernels the bench runs:
+#   (2, 64, 96), (1, 160, 160): W >= 64 and H >= 32 -> the 16x32 "big" tile of the 16->16 units;
+#   (40, 80, 80): 2000 tiles of 8x16 > the persistent grid (256 workgroups backward, <= 1024
+#   forward) -> every workgroup walks >= 3 tiles through the issue(t + gridDim.x) prefetch path;
+#   (70, 20, 20): packed canvas with 5 canvas rows -> 30 x 10 = 300 packed tiles > 256 workgroups.
+BIG_SHAPES = {(16, 16): [(2, 64, 96), (1, 160, 160), (9, 96, 128)],
+              (64, 64): [(40, 80, 80), (70, 20, 20)],
+              (16, 64): [(40, 80, 80)],
+              (64, 16): [(40, 80, 80), (70, 20, 20)]}
+
+
+def shapes_for(cin, cout):
+    return SHAPES + BIG_SHAPES.get((cin, cout), [])
+
+
 CHANNELS = [(16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64), (64, 16)]
 
 
@@ -59,7 +74,7 @@ CHANNELS = [(16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64), (64, 16)
 def test_dp_fwd(cin, cout, with_in_bn):
     k = K()
     g = torch.Generator().manual_seed(cin * 100 + cout)
-    for (n, h, w) in SHAPES:
+    for (n, h, w) in shapes_for(cin, cout):
         x = torch.randn(n, cin, h, w, generator=g) * 3 + 1.5
         w_pw, b_pw, w_dw, b_dw = mk_unit(cin, cout, g)
         gamma = torch.rand(cin, generator=g) + 0.5
@@ -92,7 +107,7 @@ def test_dp_bwd(cin, cout, mode):
     g = torch.Generator().manual_seed(7 + cin * 100 + cout)
     in_bn_on = mode.startswith('bn')
     out_bn_on = mode.endswith('_bn')
-    for (n, h, w) in SHAPES[:3]:
+    for (n, h, w) in shapes_for(cin, cout):
         x = (torch.randn(n, cin, h, w, generator=g) * 2 + 0.5).double()
         w_pw, b_pw, w_dw, b_dw = [t.double().requires_grad_(True) for t in mk_unit(cin, cout, g)]
         gi, bi = (torch.rand(cin, generator=g) + 0.5).double(), (torch.randn(cin, generator=g) * .2).double()
