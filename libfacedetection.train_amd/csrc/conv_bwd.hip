@@ -16,8 +16,21 @@ namespace {
 
 #define BWD_THREADS 512
 #define BWD_WAVES 8
+// Where the split-bf16 variant issues the next tile's global loads: 1 = right after the stage (the
+// loads have the whole tile to land, 64 more live registers in the p GEMM and the VALU phase),
+// 0 = after the VALU phase like the fp32 variant (whose two long GEMMs follow and cover the latency)
+#ifndef DP_BWD_PF_EARLY
+#define DP_BWD_PF_EARLY 0
+#endif
 
-template <int CIN, int COUT, int TH, int TW>
+// GEMM = 0: the three pointwise GEMMs on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32).
+// GEMM = 1: split-bf16 -- every fp32 operand x is split on the fly into hi = bf16(x) and
+//   lo = bf16(x - hi) (x = hi + lo to 2^-17 relative) and each product runs as the three bf16
+//   MFMAs hi*hi + lo*hi + hi*lo with fp32 accumulation (v_mfma_f32_16x16x32_bf16: 16x the fp32
+//   matrix rate, so 3/16 of the matrix time).  The dropped lo*lo term is <= 2^-18 relative: the
+//   products carry ~1e-5 relative error instead of 6e-8.  Used for GRADIENTS only (backward of
+//   the 64 -> 64 units); the forward pass stays on the exact instruction.
+template <int CIN, int COUT, int TH, int TW, int GEMM = 0>
 struct BwdGeom {
     static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_;
     static constexpr int IP = TH * TW, IMT = IP / 16;
@@ -30,10 +43,11 @@ struct BwdGeom {
     // dW1 (K = pixels): a wave owns MB x NB 16x16 tiles whose rows / columns are interleaved
     // (ci = MB*m + j, co = NB*n + i), so ONE MB-float and ONE NB-float LDS read feed MB*NB
     // MFMAs; the NGRP wave groups cover [CIN x COUT], the remaining waves split K
-    static constexpr int MB = (NTI >= 2 && NTI * NTO < 16) ? 2 : 1, NB = NTO >= 2 ? 2 : 1;
+    static constexpr int MB = (NTI >= 2 && (NTI * NTO < 16 || GEMM == 1)) ? 2 : 1, NB = NTO >= 2 ? 2 : 1;
     static constexpr int NGRP = (NTI / MB) * (NTO / NB);
     static constexpr int KSPLIT = BWD_WAVES / NGRP;
     static constexpr int KSTEPS = (IP / 4) / KSPLIT;  // k-steps of 4 pixels per wave
+    static constexpr int KPX = IP / KSPLIT;           // pixels of K per wave (dW1)
     static constexpr int NDZ = (HP * C4O + BWD_THREADS - 1) / BWD_THREADS;  // (dy,z) float4 pairs / thread
     static constexpr int NX = (IP * C4I) / BWD_THREADS;                       // x float4 / thread
     // LDS carve (floats)
@@ -41,7 +55,12 @@ struct BwdGeom {
     static constexpr int OFF_A = OFF_DZ + HP * LSO;
     static constexpr int OFF_PB = OFF_A + IP * LSI;
     static constexpr int WORK_F = OFF_PB + IP * LSO;
-    static constexpr int PAR_F = COUT * WS + 9 * COUT + 7 * COUT + 5 * CIN + CIN * WST + 4 * CIN + IP / 4;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums | validity bytes
+    // GEMM = 1: W1 and W1^T as bf16 hi / lo planes, rows padded to WSB / WSTB elements
+    static constexpr int WSB = CIN + 8, WSTB = COUT + 8;
+    static constexpr int W1_F = GEMM ? (2 * COUT * WSB) / 2 + COUT : COUT * WS;     // (+ bias row)
+    static constexpr int W1T_F = GEMM ? (2 * CIN * WSTB) / 2 : CIN * WST;
+    static constexpr int PAR_F = W1_F + 9 * COUT + 7 * COUT + 5 * CIN + W1T_F + 4 * CIN + IP / 4;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums | validity bytes
+    static_assert(GEMM == 0 || (CIN % 32 == 0 && COUT % 32 == 0 && (IP / KSPLIT) % 32 == 0), "bf16 MFMA: K in blocks of 32");
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
     static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
     static constexpr size_t WORK = (size_t)WORK_F * 4;
@@ -70,21 +89,62 @@ __device__ __forceinline__ float tin(float x, float mean, float scale, float bet
     return fmaxf(fmaf(x - mean, scale, beta), floor_);
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED>
+// ---- split-bf16 helpers (GEMM = 1) --------------------------------------------------------------
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> packed bf16 pairs hi = rne(x), lo = rne(x - hi); element 0 in the low half
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {x0 - __uint_as_float(hb << 16), x1 - __uint_as_float(hb & 0xffff0000u)};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+struct Split8 {
+    u32x4 hi, lo;     // 8 bf16 each: the 8 k-slots one lane feeds to v_mfma_f32_16x16x32_bf16
+};
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(x[2 * i], x[2 * i + 1], h[i], l[i]);
+    Split8 o;
+    o.hi = u32x4{h[0], h[1], h[2], h[3]};
+    o.lo = u32x4{l[0], l[1], l[2], l[3]};
+    return o;
+}
+// D += A*B with A = ah + al, B = bh + bl (lo*lo dropped); small terms first
+__device__ __forceinline__ f32x4 mfma3(const Split8& a, const u32x4 bh, const u32x4 bl, f32x4 c) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi), al = __builtin_bit_cast(bf16x8, a.lo);
+    const bf16x8 vh = __builtin_bit_cast(bf16x8, bh), vl = __builtin_bit_cast(bf16x8, bl);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vh, c, 0, 0, 0);
+    return c;
+}
+
+template <int CIN, int COUT, int TH, int TW, bool PACKED, int GEMM = 0>
 __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, const PackGeom pk) {
-    using G = BwdGeom<CIN, COUT, TH, TW>;
+    using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
     float* s_dz = sm + G::OFF_DZ;
     float* s_a = sm + G::OFF_A;
     float* s_pb = sm + G::OFF_PB;
     // the parameter/coefficient block sits after the (possibly larger) reduction work area
-    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);   // [COUT][WS]
-    float* s_w2 = s_w1 + COUT * G::WS;                             // [9][COUT]
+    float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);   // [COUT][WS]  (GEMM 1: bf16 planes hi | lo [COUT][WSB], then b1[COUT])
+    float* s_w2 = s_w1 + G::W1_F;                                  // [9][COUT]
     float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2|mean_lo|c1_lo
     float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
-    float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM)
-    double* s_bst = reinterpret_cast<double*>(s_w1t + CIN * G::WST);   // [2][CIN] producer's BN-backward sums
+    float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM; GEMM 1: planes hi | lo [CIN][WSTB])
+    double* s_bst = reinterpret_cast<double*>(s_w1t + G::W1T_F);   // [2][CIN] producer's BN-backward sums
+    // GEMM 1 views of the weight block
+    __bf16* s_w1h = reinterpret_cast<__bf16*>(s_w1);
+    __bf16* s_w1l = s_w1h + COUT * G::WSB;
+    float* s_b1 = reinterpret_cast<float*>(s_w1l + COUT * G::WSB);
+    __bf16* s_w1th = reinterpret_cast<__bf16*>(s_w1t);
+    __bf16* s_w1tl = s_w1th + CIN * G::WSTB;
     unsigned char* s_in = reinterpret_cast<unsigned char*>(s_bst + 2 * CIN);   // [IP] packed mode: pixel is real
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -101,9 +161,19 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 
     for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
         const float w = d.w_pw[i];
-        s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
-        if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
-        s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
+        if constexpr (GEMM == 1) {
+            const __bf16 h = (__bf16)w;
+            const __bf16 l = (__bf16)(w - (float)h);
+            s_w1h[(i / CIN) * G::WSB + (i % CIN)] = h;
+            s_w1l[(i / CIN) * G::WSB + (i % CIN)] = l;
+            s_w1th[(i % CIN) * G::WSTB + (i / CIN)] = h;
+            s_w1tl[(i % CIN) * G::WSTB + (i / CIN)] = l;
+            if (i % CIN == 0) s_b1[i / CIN] = d.b_pw[i / CIN];
+        } else {
+            s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
+            if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
+            s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
+        }
     }
     for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
     for (int c = tid; c < COUT; c += BWD_THREADS) {
@@ -290,9 +360,56 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
         }
         __syncthreads();
+        if (GEMM == 1 && DP_BWD_PF_EARLY && t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
 
         // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
-        if (!(abl & 1)) {
+        if constexpr (GEMM == 1) {
+            if (!(abl & 1)) {
+#pragma unroll 1
+                for (int mi = 0; mi < G::MPW; ++mi) {
+                    const int mt = wid * G::MPW + mi;
+                    f32x4 acc[G::NTO];
+#pragma unroll
+                    for (int nt = 0; nt < G::NTO; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // lane group g supplies input channels 32*kb + 8g .. +7 of pixel row l15 (A) and
+                    // of weight row nt*16 + l15 (B): the same k order on both sides
+                    const float* arow = s_a + (mt * 16 + l15) * G::LSI + 8 * g;
+                    const float* crow = s_ci + 8 * g;
+                    const __bf16* bh = s_w1h + l15 * G::WSB + 8 * g;
+                    const __bf16* bl = s_w1l + l15 * G::WSB + 8 * g;
+#pragma unroll
+                    for (int kb = 0; kb < CIN / 32; ++kb) {
+                        float a8[8];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 xv = *reinterpret_cast<const float4*>(arow + 32 * kb + 4 * h);
+                            const float4 mv = *reinterpret_cast<const float4*>(crow + 32 * kb + 4 * h);
+                            const float4 sv = *reinterpret_cast<const float4*>(crow + CIN + 32 * kb + 4 * h);
+                            const float4 tv = *reinterpret_cast<const float4*>(crow + 2 * CIN + 32 * kb + 4 * h);
+                            a8[4 * h + 0] = tin(xv.x, mv.x, sv.x, tv.x, relu_floor);
+                            a8[4 * h + 1] = tin(xv.y, mv.y, sv.y, tv.y, relu_floor);
+                            a8[4 * h + 2] = tin(xv.z, mv.z, sv.z, tv.z, relu_floor);
+                            a8[4 * h + 3] = tin(xv.w, mv.w, sv.w, tv.w, relu_floor);
+                        }
+                        const Split8 as = split8(a8);
+#pragma unroll
+                        for (int nt = 0; nt < G::NTO; ++nt) {
+                            const u32x4 vh = *reinterpret_cast<const u32x4*>(bh + nt * 16 * G::WSB + 32 * kb);
+                            const u32x4 vl = *reinterpret_cast<const u32x4*>(bl + nt * 16 * G::WSB + 32 * kb);
+                            acc[nt] = mfma3(as, vh, vl, acc[nt]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ip = mt * 16 + 4 * g + r;
+                        const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
+#pragma unroll
+                        for (int nt = 0; nt < G::NTO; ++nt)
+                            s_pb[ip * G::LSO + nt * 16 + l15] = in ? acc[nt][r] + s_b1[nt * 16 + l15] : 0.0f;
+                    }
+                }
+            }
+        } else if (!(abl & 1)) {
 #pragma unroll 1
             for (int mi = 0; mi < G::MPW; ++mi) {
                 const int mt = wid * G::MPW + mi;
@@ -364,10 +481,19 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         // once with a sliding window: each dz value is read from LDS one time and feeds every
         // output row it touches (3x fewer LDS reads than tap-by-tap when PPT = 4).
         if (!(abl & 2)) {
+            // thread coordinates re-derived from an opaque copy of tid: all LDS addresses of this phase
+            // become ONE per-tile base register + compile-time offsets (hoisted out of the tile loop
+            // they are ~30 separate address registers, which the allocator then spills)
+            const int tv = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
+            const int cq = tv % G::C4O, pg = tv / G::C4O;
+            const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
+            const float* zb = s_dz + (vr0 * G::HW_ + vtx) * G::LSO + cq * 4;
+            float* pb = s_pb + (vr0 * TW + vtx) * G::LSO + cq * 4;
+            const float* wb = s_w2 + cq * 4;
             float4 pv[G::PPT], dp[G::PPT];
 #pragma unroll
             for (int r = 0; r < G::PPT; ++r) {
-                pv[r] = *reinterpret_cast<const float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4);
+                pv[r] = *reinterpret_cast<const float4*>(pb + r * TW * G::LSO);
                 dp[r] = make_float4(0, 0, 0, 0);
             }
 #pragma unroll
@@ -375,11 +501,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 float4 wk[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    wk[a] = *reinterpret_cast<const float4*>(s_w2 + (8 - (3 * a + b)) * COUT + cq * 4);
+                    wk[a] = *reinterpret_cast<const float4*>(wb + (8 - (3 * a + b)) * COUT);
 #pragma unroll
                 for (int j = 0; j < G::PPT + 2; ++j) {
-                    const float4 z4 = *reinterpret_cast<const float4*>(
-                        s_dz + ((vr0 + j) * G::HW_ + vtx + b) * G::LSO + cq * 4);
+                    const float4 z4 = *reinterpret_cast<const float4*>(zb + (j * G::HW_ + b) * G::LSO);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         const int r = j - a;
@@ -402,16 +527,67 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 const bool in = inside((vr0 + r) * TW + vtx, y0 + vr0 + r, x0 + vtx);
                 if (!in) dp[r] = make_float4(0, 0, 0, 0);
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
-                *reinterpret_cast<float4*>(s_pb + ((vr0 + r) * TW + vtx) * G::LSO + cq * 4) = dp[r];
+                *reinterpret_cast<float4*>(pb + r * TW * G::LSO) = dp[r];
             }
         }
         __syncthreads();
         // prefetch the next tile's global data; issued here (not right after the stage) so that the
         // p GEMM and the VALU phase run without ~64 prefetch registers live -- the two GEMMs, the
         // mask phase and the store that follow are several microseconds, enough for HBM
-        if (t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
+        if (!(GEMM == 1 && DP_BWD_PF_EARLY) && t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
 
         // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
+        if constexpr (GEMM == 1) {
+            if (!(abl & 4)) {
+                static_assert(GEMM == 0 || (G::MB == 2 && G::NB == 2), "bf16 dW1: 2x2 interleaved tiles");
+                // K = pixels.  Within a block of 32 pixels lane group g supplies rows 8g .. 8g+7 of BOTH
+                // operands (8-byte reads of 2 interleaved channels, rows 8 apart between lane groups:
+                // conflict-free for ds_read_b64 with the 68-float row stride)
+                const float* ap = s_a + (w1_kslice * G::KPX + 8 * g) * G::LSI + w1_ci0 + 2 * l15;
+                const float* bp = s_pb + (w1_kslice * G::KPX + 8 * g) * G::LSO + w1_co0 + 2 * l15;
+                float am[2], as_[2], ab[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ca = w1_ci0 + 2 * (G::LAUNDER ? opaque(l15) : l15) + j;
+                    am[j] = s_ci[ca]; as_[j] = s_ci[CIN + ca]; ab[j] = s_ci[2 * CIN + ca];
+                }
+#pragma unroll 1
+                for (int kb = 0; kb < G::KPX / 32; ++kb) {
+                    // dp first (split once, used by both ci tiles), then one ci tile at a time: at most
+                    // 16 raw floats + 24 packed operand registers are live
+                    Split8 sd0, sd1;
+                    {
+                        float d0[8], d1[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float2 dv = *reinterpret_cast<const float2*>(bp + (32 * kb + t) * G::LSO);
+                            d0[t] = dv.x; d1[t] = dv.y;
+                        }
+                        sd0 = split8(d0);
+                        sd1 = split8(d1);
+                    }
+                    float2 av[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) av[t] = *reinterpret_cast<const float2*>(ap + (32 * kb + t) * G::LSI);
+                    {
+                        float a0[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) a0[t] = tin(av[t].x, am[0], as_[0], ab[0], relu_floor);
+                        const Split8 sa0 = split8(a0);
+                        gw1[0] = mfma3(sa0, sd0.hi, sd0.lo, gw1[0]);
+                        gw1[1] = mfma3(sa0, sd1.hi, sd1.lo, gw1[1]);
+                    }
+                    {
+                        float a1[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) a1[t] = tin(av[t].y, am[1], as_[1], ab[1], relu_floor);
+                        const Split8 sa1 = split8(a1);
+                        gw1[2] = mfma3(sa1, sd0.hi, sd0.lo, gw1[2]);
+                        gw1[3] = mfma3(sa1, sd1.hi, sd1.lo, gw1[3]);
+                    }
+                }
+            }
+        } else
         if (!(abl & 4)) {
             const float* ap = s_a + (w1_kslice * G::KSTEPS * 4 + g) * G::LSI + w1_ci0 + G::MB * l15;
             const float* bp = s_pb + (w1_kslice * G::KSTEPS * 4 + g) * G::LSO + w1_co0 + G::NB * l15;
@@ -450,7 +626,32 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         for (int mi = 0; mi < G::MPW; ++mi)
 #pragma unroll
             for (int nt = 0; nt < G::NTI; ++nt) da[mi][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(abl & 8)) {
+        if constexpr (GEMM == 1) {
+            if (!(abl & 8)) {
+#pragma unroll
+                for (int mi = 0; mi < G::MPW; ++mi) {
+                    // k = output channels: lane group g supplies channels 32*kb + 8g .. +7
+                    const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + 8 * g;
+                    const __bf16* wh = s_w1th + l15 * G::WSTB + 8 * g;
+                    const __bf16* wl = s_w1tl + l15 * G::WSTB + 8 * g;
+#pragma unroll
+                    for (int kb = 0; kb < COUT / 32; ++kb) {
+                        float p8[8];
+                        const float4 v0 = *reinterpret_cast<const float4*>(prow + 32 * kb);
+                        const float4 v1 = *reinterpret_cast<const float4*>(prow + 32 * kb + 4);
+                        p8[0] = v0.x; p8[1] = v0.y; p8[2] = v0.z; p8[3] = v0.w;
+                        p8[4] = v1.x; p8[5] = v1.y; p8[6] = v1.z; p8[7] = v1.w;
+                        const Split8 ps = split8(p8);
+#pragma unroll
+                        for (int nt = 0; nt < G::NTI; ++nt) {
+                            const u32x4 vh = *reinterpret_cast<const u32x4*>(wh + nt * 16 * G::WSTB + 32 * kb);
+                            const u32x4 vl = *reinterpret_cast<const u32x4*>(wl + nt * 16 * G::WSTB + 32 * kb);
+                            da[mi][nt] = mfma3(ps, vh, vl, da[mi][nt]);
+                        }
+                    }
+                }
+            }
+        } else if (!(abl & 8)) {
 #pragma unroll
             for (int mi = 0; mi < G::MPW; ++mi) {
                 const float* prow = s_pb + ((wid * G::MPW + mi) * 16 + l15) * G::LSO + 4 * g;
@@ -490,7 +691,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 const int c = nt * 16 + (G::LAUNDER ? opaque(l15) : l15);   // (keeps the 5*NTI coefficients out of loop-invariant registers)
                 const float cm = s_ci[c], cs = s_ci[CIN + c], cb = s_ci[2 * CIN + c], ci = s_ci[3 * CIN + c];
                 const float cl = s_ci[4 * CIN + c];
-                double t0 = 0.0, t1 = 0.0;
+                // Sums of this wave's 16 * MPW pixels in fp32 (a handful of terms: rounding 1e-7 of the
+                // partial), folded over the four lane groups with two cross-lane adds; only then fp64 and
+                // ONE LDS atomic per channel and wave (the long, heavily cancelling accumulation over the
+                // whole tensor stays in fp64).  64 lanes x 2 fp64 atomics on 16 addresses per channel block
+                // used to serialise in the LDS.
+                float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
                 for (int mi = 0; mi < G::MPW; ++mi)
 #pragma unroll
@@ -500,12 +706,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                         const float xr = *ap;
                         const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
                         const float v = (in && fmaf(xr - cm, cs, cb) > 0.0f) ? da[mi][nt][r] : 0.0f;   // ReLU mask
-                        t0 += (double)v;
-                        t1 += (double)(v * (bn_center(xr, cm, cl) * ci));
+                        t0 += v;
+                        t1 = fmaf(v, bn_center(xr, cm, cl) * ci, t1);
                         *ap = v;
                     }
-                __hip_atomic_fetch_add(s_bst + c, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(s_bst + CIN + c, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64);
+                t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
+                if (g == 0) {
+                    __hip_atomic_fetch_add(s_bst + c, (double)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(s_bst + CIN + c, (double)t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         } else {
 #pragma unroll
@@ -610,12 +820,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED = false>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0>
 int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
-    using G = BwdGeom<CIN, COUT, TH, TW>;
+    using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
@@ -627,7 +837,7 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
+    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
                        stream, *d, pk);
     return hip_status();
 }
@@ -1028,8 +1238,15 @@ extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
     if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))
         return launch_dp_bwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
-    if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout))             // 20x20 / 10x10 levels: packed canvas
-        return d->cout == 64 ? launch_dp_bwd<64, 64, 8, 16, true>(d, s) : launch_dp_bwd<64, 16, 8, 16, true>(d, s);
+    // 64 -> 64 units: split-bf16 GEMMs (gradients only); YUNET_BWD_FP32MMA=1 keeps the exact-fp32
+    // matrix instruction (A/B measurements, tools/kbench.py)
+    const bool f32mma = getenv("YUNET_BWD_FP32MMA") != nullptr;
+    if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout)) {           // 20x20 / 10x10 levels: packed canvas
+        if (d->cout == 64)
+            return f32mma ? launch_dp_bwd<64, 64, 8, 16, true>(d, s) : launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s);
+        return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
+    }
+    if (d->cin == 64 && d->cout == 64 && !f32mma) return launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

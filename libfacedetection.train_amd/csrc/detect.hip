@@ -38,13 +38,13 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);            // [padn]
     float4* sbox = reinterpret_cast<float4*>(smem + (size_t)padn * 8);                 // [DET_BOX_CAP]
-    __shared__ int s_k, s_keep;
+    __shared__ int s_k;
     const int n = blockIdx.x, tid = threadIdx.x;
     const float* f = flat + (size_t)n * P * 16;
     float4* gbox = scratch + (size_t)n * P;
 
     // ---- scores and keys ------------------------------------------------------------------------
-    if (tid == 0) { s_k = 0; s_keep = 0; }
+    if (tid == 0) s_k = 0;
     for (int p = tid; p < padn; p += DET_THREADS) {
         unsigned long long key = 0ull;
         if (p < P) {
@@ -89,10 +89,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(
     // ---- greedy NMS in score order ---------------------------------------------------------------------
     float* dn = dets + (size_t)n * max_out * 5;
     float* kn = kps_out ? kps_out + (size_t)n * max_out * 10 : nullptr;
+    // `kept` lives in a register of EVERY thread: keys[i] is uniform after the barrier that ends the
+    // previous iteration, so all threads count the same survivors and take the same break (a shared
+    // counter written by thread 0 mid-iteration could be read before or after that write)
+    int kept = 0;
     for (int i = 0; i < K; ++i) {
         const unsigned long long key_i = keys[i];   // 0 = suppressed (written before the last barrier)
         if (key_i == 0ull) continue;
-        const int o = s_keep;
+        const int o = kept;
         if (o >= max_out) break;
         const float4 bi = i < DET_BOX_CAP ? sbox[i] : gbox[i];
         for (int j = i + 1 + tid; j < K; j += DET_THREADS) {
@@ -115,12 +119,11 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(
                     kn[o * 10 + 2 * t + 1] = q[2 * t + 1] * s + py;
                 }
             }
-            s_keep = o + 1;
         }
+        kept = o + 1;
         __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) count[n] = s_keep;
+    if (tid == 0) count[n] = kept;
 }
 
 }  // namespace

@@ -1,0 +1,188 @@
+"""WIDER-Face average precision (easy / medium / hard) of a prediction set.
+
+Reference: mmdet/core/evaluation/widerface.py:152-347 (`norm_score`, `image_eval`,
+`img_pr_info`, `dataset_pr_info`, `voc_ap`, `wider_evaluation`), called by
+tools/test_widerface.py:177 as ``wider_evaluation(results, gt_path, 0.5)``.
+
+Same inputs and the same float64 arithmetic, organised per image as array operations instead
+of the reference's per-prediction Python loop over a multiprocessing pool:
+
+* the IoU of every (prediction, GT) pair is one matrix (the "+1" pixel convention of the
+  protocol: w = x2 - x1 + 1);
+* the greedy matching is sequential only through "has this kept GT been hit before", which
+  is a first-occurrence mask + cumulative sum;
+* the 1000-threshold precision / recall counters of an image come from one boolean
+  [threshold, prediction] matrix.
+
+`pred` is {event: {image name: float array [n, 5] = x, y, w, h, score}} (rows in descending
+score, as get_bboxes delivers them); `gt_path` holds the four protocol files
+wider_{face,easy,medium,hard}_val.mat.  Host side only (numpy): evaluation is not part of the
+training hot path.
+"""
+import os
+
+import numpy as np
+
+THRESH_NUM = 1000
+
+
+# ------------------------------------------------------------------------------- ground truth
+def load_wider_gt(gt_dir):
+    """-> list of events: dict(name, images=[dict(name, boxes [g,4] xywh float64,
+    keep={'easy'|'medium'|'hard': 1-based index array})])."""
+    from scipy.io import loadmat
+    face = loadmat(os.path.join(gt_dir, 'wider_face_val.mat'))
+    subsets = {k: loadmat(os.path.join(gt_dir, f'wider_{k}_val.mat'))['gt_list']
+               for k in ('easy', 'medium', 'hard')}
+    events = []
+    for i in range(len(face['event_list'])):
+        ev = dict(name=str(face['event_list'][i][0][0]), images=[])
+        files, boxes = face['file_list'][i][0], face['face_bbx_list'][i][0]
+        for j in range(len(files)):
+            keep = {k: np.asarray(subsets[k][i][0][j][0]).reshape(-1).astype(np.int64) for k in subsets}
+            ev['images'].append(dict(name=str(files[j][0][0]),
+                                     boxes=np.asarray(boxes[j][0], dtype=np.float64).reshape(-1, 4),
+                                     keep=keep))
+        events.append(ev)
+    return events
+
+
+# --------------------------------------------------------------------------------- predictions
+def read_predictions(pred_dir):
+    """The per-image text files tools/test_widerface.py --save-preds writes
+    (<event>/<image>.txt: name, count, then `x y w h score` rows) -> the `pred` dict."""
+    pred = {}
+    for event in sorted(os.listdir(pred_dir)):
+        edir = os.path.join(pred_dir, event)
+        if not os.path.isdir(edir):
+            continue
+        cur = {}
+        for fn in sorted(os.listdir(edir)):
+            with open(os.path.join(edir, fn)) as f:
+                lines = f.read().splitlines()
+            name = lines[0].split('/')[-1]
+            rows = [[float(v) for v in ln.split(' ')] for ln in lines[2:] if ln.strip()]
+            cur[name[:-4] if name.endswith('.jpg') else name] = \
+                np.asarray(rows, dtype=np.float64).reshape(-1, 5)
+        pred[event] = cur
+    return pred
+
+
+def write_predictions(pred_dir, event, image_name, boxes_xyxy_score):
+    """One image in the protocol's text format (tools/test_widerface.py:150-165)."""
+    os.makedirs(os.path.join(pred_dir, event), exist_ok=True)
+    b = np.asarray(boxes_xyxy_score, dtype=np.float64).reshape(-1, 5)
+    with open(os.path.join(pred_dir, event, image_name + '.txt'), 'w') as f:
+        f.write(f'{event}/{image_name}.jpg\n{b.shape[0]}\n')
+        for r in b:
+            f.write('%.5f %.5f %.5f %.5f %g\n' % (r[0], r[1], r[2] - r[0], r[3] - r[1], r[4]))
+
+
+def norm_score(pred):
+    """Min-max normalisation of every score over the WHOLE prediction set, in place
+    (widerface.py:152-174)."""
+    lo, hi = 2.0, -1.0
+    for ev in pred.values():
+        for v in ev.values():
+            if len(v):
+                lo, hi = min(lo, float(np.min(v[:, -1]))), max(hi, float(np.max(v[:, -1])))
+    diff = hi - lo
+    for ev in pred.values():
+        for v in ev.values():
+            if len(v):
+                v[:, -1] = (v[:, -1] - lo).astype(np.float64) / diff
+    return pred
+
+
+# --------------------------------------------------------------------------------- one image
+def pairwise_iou_xywh(pred, gt):
+    """[n_pred, n_gt] IoU with the protocol's inclusive-pixel convention (widerface.py:39-52)."""
+    p = np.asarray(pred, dtype=np.float64)
+    g = np.asarray(gt, dtype=np.float64)
+    px2, py2 = p[:, 0] + p[:, 2], p[:, 1] + p[:, 3]
+    gx2, gy2 = g[:, 0] + g[:, 2], g[:, 1] + g[:, 3]
+    w = np.minimum(gx2[None, :], px2[:, None]) - np.maximum(g[None, :, 0], p[:, None, 0]) + 1
+    h = np.minimum(gy2[None, :], py2[:, None]) - np.maximum(g[None, :, 1], p[:, None, 1]) + 1
+    inter = w * h
+    ga = (gx2 - g[:, 0] + 1) * (gy2 - g[:, 1] + 1)
+    pa = (px2 - p[:, 0] + 1) * (py2 - p[:, 1] + 1)
+    o = inter / (ga[None, :] + pa[:, None] - inter)
+    o[(w <= 0) | (h <= 0)] = 0
+    return o
+
+
+def image_eval(pred, gt, keep_flag, iou_thresh):
+    """Greedy matching of one image (widerface.py:177-215).
+
+    keep_flag[g] = 1 for the GTs of the current difficulty subset.  Returns
+    pred_recall[h] = subset GTs recalled by predictions 0..h, and proposal[h] = -1 for
+    predictions whose best GT lies outside the subset (not counted as false positives), else 1."""
+    n = pred.shape[0]
+    iou = pairwise_iou_xywh(pred[:, :4], gt)
+    best = iou.argmax(axis=1)
+    hit = iou[np.arange(n), best] >= iou_thresh
+    in_subset = keep_flag[best] == 1
+    proposal = np.where(hit & ~in_subset, -1.0, 1.0)
+    counted = hit & in_subset
+    first = np.zeros(n, dtype=bool)
+    if counted.any():
+        idx = np.nonzero(counted)[0]
+        _, first_pos = np.unique(best[idx], return_index=True)     # first prediction per GT
+        first[idx[first_pos]] = True
+    return np.cumsum(first).astype(np.float64), proposal
+
+
+def img_pr_info(scores, proposal, pred_recall, thresh_num=THRESH_NUM):
+    """[thresh_num, 2] = (#counted predictions, #recalled GTs) at score thresholds
+    1 - (t+1)/thresh_num (widerface.py:218-239): taken at the LAST prediction whose score
+    passes the threshold."""
+    thresh = np.array([1 - (t + 1) / thresh_num for t in range(thresh_num)])
+    ok = scores[None, :] >= thresh[:, None]
+    any_ok = ok.any(axis=1)
+    last = scores.shape[0] - 1 - np.argmax(ok[:, ::-1], axis=1)
+    cum_prop = np.cumsum(proposal == 1).astype(np.float64)
+    out = np.zeros((thresh_num, 2))
+    out[any_ok, 0] = cum_prop[last[any_ok]]
+    out[any_ok, 1] = pred_recall[last[any_ok]]
+    return out
+
+
+def voc_ap(rec, prec):
+    """Area under the precision envelope (widerface.py:250-268)."""
+    mrec = np.concatenate(([0.], rec, [1.]))
+    mpre = np.concatenate(([0.], prec, [0.]))
+    mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+
+
+# ----------------------------------------------------------------------------------- dataset
+def wider_evaluation(pred, gt_path, iou_thresh=0.5, return_curves=False):
+    """-> [AP_easy, AP_medium, AP_hard] (widerface.py:271-347).  `pred` scores are normalised in
+    place, as in the reference."""
+    pred = norm_score(pred)
+    events = load_wider_gt(gt_path) if isinstance(gt_path, (str, os.PathLike)) else gt_path
+    aps, curves = [], []
+    for setting in ('easy', 'medium', 'hard'):
+        count_face = 0
+        pr = np.zeros((THRESH_NUM, 2))
+        for ev in events:
+            plist = pred[ev['name']]
+            for im in ev['images']:
+                info = plist[im['name']]
+                keep = im['keep'][setting]
+                count_face += len(keep)
+                if len(im['boxes']) == 0 or len(info) == 0:
+                    continue
+                flag = np.zeros(im['boxes'].shape[0], dtype=np.int64)
+                if len(keep):
+                    flag[keep - 1] = 1
+                info = np.asarray(info, dtype=np.float64)
+                rec, prop = image_eval(info, im['boxes'], flag, iou_thresh)
+                pr += img_pr_info(info[:, 4], prop, rec)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            precision = pr[:, 1] / pr[:, 0]
+            recall = pr[:, 1] / count_face
+        aps.append(float(voc_ap(recall, precision)))
+        curves.append(np.stack([precision, recall], 1))
+    return (aps, curves) if return_curves else aps

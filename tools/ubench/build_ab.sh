@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds the torch-free backward A/B harness and variant libraries of libyunet_hip.so:
+#   tools/ubench/build_ab.sh [NAME "EXTRA_HIPCC_FLAGS"] ...
+# -> tools/ubench/bwd_ab.bin, and for every NAME a libyunet_NAME.so next to it whose conv_bwd.o was
+#    compiled with the extra flags (the other objects are shared with the product build).
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+CSRC=$ROOT/libfacedetection.train_amd/csrc
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+make -C $CSRC -j8 >/dev/null
+$HIPCC --offload-arch=gfx950 -O2 $ROOT/tools/ubench/bwd_ab.cpp -o $ROOT/tools/ubench/bwd_ab.bin -ldl
+while [ $# -ge 2 ]; do
+  name=$1; extra=$2; shift 2
+  $HIPCC $FLAGS $extra -c $CSRC/conv_bwd.hip -o /tmp/conv_bwd_$name.o
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o $CSRC/conv_fwd.o /tmp/conv_bwd_$name.o \
+      $CSRC/augment.o $CSRC/detect.o $CSRC/api.o -o $ROOT/tools/ubench/libyunet_$name.so
+  echo built libyunet_$name.so
+done
