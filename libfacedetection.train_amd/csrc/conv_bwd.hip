@@ -12,6 +12,8 @@
 // da = dp * W1 (MFMA); dx = da * relu-mask, BN-backward sums of the producer.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 #define BWD_THREADS 512
@@ -21,6 +23,22 @@ namespace {
 // 0 = after the VALU phase like the fp32 variant (whose two long GEMMs follow and cover the latency)
 #ifndef DP_BWD_PF_EARLY
 #define DP_BWD_PF_EARLY 0
+#endif
+#ifndef DP_BWD_PF_SPREAD
+#define DP_BWD_PF_SPREAD 1
+#endif
+// -DDP_BWD_PROF: per-workgroup phase cycle counters (tools/ubench/bwd_ab: PROF=1).  d.prof then points to
+// [grid][8] uint64: cycles of wave 0 between the barriers that end stage | p GEMM | depthwise | dW1 + da |
+// mask | store, summed over the workgroup's tiles.  Not in the product build (it costs registers).
+#ifdef DP_BWD_PROF
+#define DP_BWD_STAMP(k)                                                        \
+    if (prof_on && threadIdx.x == 0) {                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();          \
+        prof_acc[k] += now_ - prof_t;                                          \
+        prof_t = now_;                                                         \
+    }
+#else
+#define DP_BWD_STAMP(k)
 #endif
 
 // GEMM = 0: the three pointwise GEMMs on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32).
@@ -244,8 +262,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     unsigned okmask = 0;
     const unsigned zbytes = (unsigned)(H * W * COUT) * 4u, xbytes = (unsigned)(H * W * CIN) * 4u;
     constexpr int PSTEP = BWD_THREADS / G::C4O;            // halo pixels between a thread's slots
-    constexpr int HSTEP_Y = PSTEP / G::HW_, HSTEP_X = PSTEP % G::HW_;
-    auto issue = [&](int t) {
+    // issue(t, part): part -1 = everything at once; parts 0..3 = x | first | second | last third of the
+    // (dy, z) slots.  A CU keeps far fewer bytes in flight than the 124 KB of a tile: issued in one go
+    // the waves sit in the issue for the time the transfer takes (measured 5.8 k cycles per tile with
+    // the per-phase counters); in four pieces between the phases the transfer runs under the compute.
+    auto issue = [&](int t, auto part_c) {
+        constexpr int PART = decltype(part_c)::value;
         const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
@@ -258,11 +280,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy) + zbase, 0, zrange, 0x00020000);
         const auto r_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z) + zbase, 0, zrange, 0x00020000);
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + xbase, 0, xrange, 0x00020000);
-        int hp = tid / G::C4O;
-        int hy = hp / G::HW_, hx = hp - hy * G::HW_;
-        okmask = 0;
+        if (PART <= 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < G::NDZ; ++i) {
+            if (PART >= 0 && PART != 1 + (3 * i) / G::NDZ) continue;
+            const int hp = tid / G::C4O + PSTEP * i;
+            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             bool ok;
             unsigned off;
@@ -282,14 +305,13 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 const u32x4 vz = __builtin_amdgcn_raw_buffer_load_b128(r_z, off, 0, 0);
                 pz[i] = *reinterpret_cast<const float4*>(&vz);
             }
-            hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
-            if (hx >= G::HW_) { hx -= G::HW_; ++hy; }
             // packed: finish one slot's address arithmetic before the next one starts (otherwise
             // all 16 canvas -> image mappings are computed up front and spill)
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < G::NX; ++i) {
+            if (PART > 0) continue;
             const int ip = (tid + BWD_THREADS * i) / G::C4I;
             const int y = y0 + ip / TW, x = x0 + ip % TW;
             unsigned off;
@@ -307,7 +329,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     };
 
     int t = blockIdx.x;
-    if (t < ntiles) issue(t);
+    using All = std::integral_constant<int, -1>;
+    constexpr bool SPREAD = GEMM == 1 && DP_BWD_PF_SPREAD;     // next tile's loads in four pieces
+    const bool pf_on = !(abl & 32);
+    if (t < ntiles) issue(t, All{});
+#ifdef DP_BWD_PROF
+    const bool prof_on = (unsigned long long)d.prof >= 4096ull;
+    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     for (; t < ntiles; t += gridDim.x) {
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
@@ -360,7 +390,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
         }
         __syncthreads();
-        if (GEMM == 1 && DP_BWD_PF_EARLY && t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
+        DP_BWD_STAMP(0);
+        const bool more = t + (int)gridDim.x < ntiles && pf_on;
+        if (SPREAD) { if (more) issue(t + gridDim.x, std::integral_constant<int, 0>{}); }
+        else if (GEMM == 1 && DP_BWD_PF_EARLY && more) issue(t + gridDim.x, All{});
 
         // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
         if constexpr (GEMM == 1) {
@@ -475,6 +508,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
         }
         __syncthreads();
+        DP_BWD_STAMP(1);
+        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, 1>{});
 
         // ---- depthwise backward on the VALU; dp overwrites p in place ----------------------------
         // A thread owns a channel quad and a column of PPT rows.  The dz column triple is walked
@@ -531,10 +566,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
         }
         __syncthreads();
+        DP_BWD_STAMP(2);
         // prefetch the next tile's global data; issued here (not right after the stage) so that the
         // p GEMM and the VALU phase run without ~64 prefetch registers live -- the two GEMMs, the
         // mask phase and the store that follow are several microseconds, enough for HBM
-        if (!(GEMM == 1 && DP_BWD_PF_EARLY) && t + (int)gridDim.x < ntiles && !(abl & 32)) issue(t + gridDim.x);
+        if (SPREAD) { if (more) issue(t + gridDim.x, std::integral_constant<int, 2>{}); }
+        else if (!(GEMM == 1 && DP_BWD_PF_EARLY) && more) issue(t + gridDim.x, All{});
 
         // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
         if constexpr (GEMM == 1) {
@@ -621,6 +658,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 }
             }
         }
+        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
         f32x4 da[G::MPW][G::NTI];
 #pragma unroll
         for (int mi = 0; mi < G::MPW; ++mi)
@@ -685,6 +723,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             }
         }
         __syncthreads();  // every wave is done reading s_a for dW1
+        DP_BWD_STAMP(3);
         if (bn_in) {
 #pragma unroll
             for (int nt = 0; nt < G::NTI; ++nt) {
@@ -727,6 +766,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                         s_a[((wid * G::MPW + mi) * 16 + 4 * g + r) * G::LSI + nt * 16 + l15] = da[mi][nt][r];
         }
         __syncthreads();
+        DP_BWD_STAMP(4);
 
         // ---- dx store (coalesced) + BN-backward sums of the producer ------------------------------
         if (d.dx && !(abl & 16)) {
@@ -736,7 +776,6 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(
                 d.dx + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
             unsigned off[G::NX];
-            u32x4 old[G::NX];
 #pragma unroll
             for (int i = 0; i < G::NX; ++i) {
                 const int ip = (tid + BWD_THREADS * i) / G::C4I;
@@ -748,23 +787,39 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 } else {
                     off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
                 }
-                if (d.accumulate_dx) old[i] = __builtin_amdgcn_raw_buffer_load_b128(r_dx, off[i], 0, 0);
             }
+            // two separate paths: the plain store must not wait on the vector-memory counter (the next
+            // tile's prefetch is in flight and the counter is in-order), only dx += reads memory
+            if (d.accumulate_dx) {
+                u32x4 old[G::NX];
 #pragma unroll
-            for (int i = 0; i < G::NX; ++i) {
-                const int ip = (tid + BWD_THREADS * i) / G::C4I;
-                float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
-                if (d.accumulate_dx) {
+                for (int i = 0; i < G::NX; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(r_dx, off[i], 0, 0);
+#pragma unroll
+                for (int i = 0; i < G::NX; ++i) {
+                    const int ip = (tid + BWD_THREADS * i) / G::C4I;
+                    float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
                     const float4 o = *reinterpret_cast<const float4*>(&old[i]);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < G::NX; ++i) {
+                    const int ip = (tid + BWD_THREADS * i) / G::C4I;
+                    const float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                }
             }
         }
         __syncthreads();
+        DP_BWD_STAMP(5);
     }
 
     // ============ flush per-workgroup partial sums ==============================================
+#ifdef DP_BWD_PROF
+    if (prof_on && threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) d.prof[blockIdx.x * 8 + k] = prof_acc[k];
+#endif
     float* row = d.wgrad_partials + (size_t)blockIdx.x * G::WROW;
     // (a) dW1: MFMA accumulators -> LDS [COUT][CIN] (summing the K slices in a fixed order)
     float* s_gw1 = sm;  // COUT*CIN floats, fits in the work area

@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
         const int ci = sh.ci, co = sh.co, H = sh.h, W = sh.w;
+        if (getenv("ONLY") && atoi(getenv("ONLY")) != H) continue;
         const size_t px = (size_t)N * H * W;
         std::vector<float> x(px * ci), z(px * co), dy(px * co), wp(co * ci), bp(co), wd(co * 9), bd(co);
         for (auto& v : x) v = grand() * 2.0f + 0.5f;
@@ -177,6 +178,12 @@ int main(int argc, char** argv) {
             // ABL=<mask>: the kernel's debug ablation mask (1 p GEMM, 2 depthwise, 4 dW1, 8 da, 16 dx
             // store, 32 next-tile prefetch are SKIPPED); results are then wrong, only the time matters
             if (getenv("ABL")) d.prof = (unsigned long long*)(uintptr_t)atoll(getenv("ABL"));
+            unsigned long long* dprof = nullptr;
+            if (getenv("PROF")) {     // libraries built with -DDP_BWD_PROF: per-phase cycle counters
+                CK(hipMalloc(&dprof, (size_t)blocks * 64));
+                CK(hipMemset(dprof, 0, (size_t)blocks * 64));
+                d.prof = dprof;
+            }
             CK(hipMemsetAsync(dbsi, 0, 2 * ci * 8, st));
             int rc = v.bwd(&d, st);
             CK(hipStreamSynchronize(st));
@@ -213,6 +220,20 @@ int main(int argc, char** argv) {
                        H, W, ci, co, N, v.name.c_str(), ms, gbs, rel(vdx, ref_dx, 0, vdx.size()),
                        rel(vw, ref_w, 0, o1), rel(vw, ref_w, o1, o2), rel(vw, ref_w, o2, o3),
                        rel(vw, ref_w, o3, (size_t)width), rel(hb, ref_b, 0, hb.size()));
+            }
+            if (dprof) {
+                CK(hipMemset(dprof, 0, (size_t)blocks * 64));
+                v.bwd(&d, st);
+                CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hp2((size_t)blocks * 8);
+                CK(hipMemcpy(hp2.data(), dprof, hp2.size() * 8, hipMemcpyDeviceToHost));
+                double acc[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
+                for (int b = 0; b < blocks; ++b)
+                    for (int k = 0; k < 6; ++k) acc[k] += (double)hp2[(size_t)b * 8 + k] / blocks;
+                for (int k = 0; k < 6; ++k) tot += acc[k];
+                printf("    phase cycles per workgroup (mean): stage %.0f | p %.0f | dw %.0f | dW1+da %.0f | mask %.0f | store %.0f"
+                       " | total %.0f  (clock units of s_memtime)\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], tot);
+                CK(hipFree(dprof));
             }
             if (!v.env_k.empty()) unsetenv(v.env_k.c_str());
             CK(hipFree(dpart));
