@@ -27,6 +27,9 @@ namespace {
 #ifndef DP_BWD_PF_SPREAD
 #define DP_BWD_PF_SPREAD 1
 #endif
+#ifndef DP_BWD_PF_SPREAD_ALL        // also for the exact-fp32 variants (16 / 32-channel units)
+#define DP_BWD_PF_SPREAD_ALL 0
+#endif
 // -DDP_BWD_PROF: per-workgroup phase cycle counters (tools/ubench/bwd_ab: PROF=1).  d.prof then points to
 // [grid][8] uint64: cycles of wave 0 between the barriers that end stage | p GEMM | depthwise | dW1 + da |
 // mask | store, summed over the workgroup's tiles.  Not in the product build (it costs registers).
@@ -177,6 +180,9 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     // debug ablation mask (tools/kbench.py --ablate): prof < 4096 is a bit mask, not a pointer
     const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
 
+#ifdef DP_BWD_PROF
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
     for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
         const float w = d.w_pw[i];
         if constexpr (GEMM == 1) {
@@ -330,13 +336,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 
     int t = blockIdx.x;
     using All = std::integral_constant<int, -1>;
-    constexpr bool SPREAD = GEMM == 1 && DP_BWD_PF_SPREAD;     // next tile's loads in four pieces
+    // next tile's loads in four pieces (measured: -8 % on 16->16 at 160x160, -6 % on 16->64, +2 % on the
+    // 64->16 heads, which keep the single issue)
+    constexpr bool SPREAD = DP_BWD_PF_SPREAD && (GEMM == 1 || DP_BWD_PF_SPREAD_ALL || COUT >= 32 || CIN == 16);
     const bool pf_on = !(abl & 32);
     if (t < ntiles) issue(t, All{});
 #ifdef DP_BWD_PROF
     const bool prof_on = (unsigned long long)d.prof >= 4096ull;
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_readcyclecounter();
+    const unsigned long long prof_pro = prof_t - prof_t0;       // prologue: weights / coefficients -> LDS
 #endif
     for (; t < ntiles; t += gridDim.x) {
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
@@ -817,8 +826,11 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 
     // ============ flush per-workgroup partial sums ==============================================
 #ifdef DP_BWD_PROF
-    if (prof_on && threadIdx.x == 0)
+    if (prof_on && threadIdx.x == 0) {
         for (int k = 0; k < 6; ++k) d.prof[blockIdx.x * 8 + k] = prof_acc[k];
+        d.prof[blockIdx.x * 8 + 6] = prof_pro;
+    }
+    const unsigned long long prof_t1 = __builtin_readcyclecounter();
 #endif
     float* row = d.wgrad_partials + (size_t)blockIdx.x * G::WROW;
     // (a) dW1: MFMA accumulators -> LDS [COUT][CIN] (summing the K slices in a fixed order)
@@ -873,6 +885,9 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     }
     // (c) BN-backward sums of the producer: one global fp64 atomic per channel
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
+#ifdef DP_BWD_PROF
+    if (prof_on && threadIdx.x == 0) d.prof[blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - prof_t1;
+#endif
 }
 
 template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0>

@@ -227,12 +227,12 @@ int main(int argc, char** argv) {
                 CK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hp2((size_t)blocks * 8);
                 CK(hipMemcpy(hp2.data(), dprof, hp2.size() * 8, hipMemcpyDeviceToHost));
-                double acc[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
+                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
                 for (int b = 0; b < blocks; ++b)
-                    for (int k = 0; k < 6; ++k) acc[k] += (double)hp2[(size_t)b * 8 + k] / blocks;
-                for (int k = 0; k < 6; ++k) tot += acc[k];
-                printf("    phase cycles per workgroup (mean): stage %.0f | p %.0f | dw %.0f | dW1+da %.0f | mask %.0f | store %.0f"
-                       " | total %.0f  (clock units of s_memtime)\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], tot);
+                    for (int k = 0; k < 8; ++k) acc[k] += (double)hp2[(size_t)b * 8 + k] / blocks;
+                for (int k = 0; k < 8; ++k) tot += acc[k];
+                printf("    cycles per workgroup (mean): prologue %.0f | stage %.0f | p %.0f | dw %.0f | dW1+da %.0f | mask %.0f | store %.0f"
+                       " | epilogue %.0f | total %.0f\n", acc[6], acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[7], tot);
                 CK(hipFree(dprof));
             }
             if (!v.env_k.empty()) unsetenv(v.env_k.c_str());
