@@ -183,70 +183,6 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #ifdef DP_BWD_PROF
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
-    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
-        const float w = d.w_pw[i];
-        if constexpr (GEMM == 1) {
-            const __bf16 h = (__bf16)w;
-            const __bf16 l = (__bf16)(w - (float)h);
-            s_w1h[(i / CIN) * G::WSB + (i % CIN)] = h;
-            s_w1l[(i / CIN) * G::WSB + (i % CIN)] = l;
-            s_w1th[(i % CIN) * G::WSTB + (i / CIN)] = h;
-            s_w1tl[(i % CIN) * G::WSTB + (i / CIN)] = l;
-            if (i % CIN == 0) s_b1[i / CIN] = d.b_pw[i / CIN];
-        } else {
-            s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
-            if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
-            s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
-        }
-    }
-    for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
-    for (int c = tid; c < COUT; c += BWD_THREADS) {
-        if (bn_out) {
-            const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
-            s_co[c] = k.mean; s_co[COUT + c] = k.invstd; s_co[2 * COUT + c] = k.k1;
-            s_co[3 * COUT + c] = k.c1; s_co[4 * COUT + c] = k.c2;
-            s_co[5 * COUT + c] = k.mean_lo; s_co[6 * COUT + c] = k.c1_lo;
-        } else {
-            s_co[c] = 0.f; s_co[COUT + c] = 0.f;
-            s_co[2 * COUT + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
-            s_co[3 * COUT + c] = 0.f; s_co[4 * COUT + c] = 0.f;
-            s_co[5 * COUT + c] = 0.f; s_co[6 * COUT + c] = 0.f;
-        }
-    }
-    for (int c = tid; c < CIN; c += BWD_THREADS) {
-        if (bn_in) {
-            const BNCoef k = bn_coef(d.in_bn, CIN, c);
-            s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
-            s_ci[3 * CIN + c] = k.invstd; s_ci[4 * CIN + c] = k.mean_lo;
-        } else {
-            s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f; s_ci[3 * CIN + c] = 1.f;
-            s_ci[4 * CIN + c] = 0.f;
-        }
-    }
-    __syncthreads();
-
-    // ---- per-thread constants ---------------------------------------------------------------
-    // VALU phase: channel quad cq, pixel column vtx, rows vr0..vr0+PPT-1
-    const int cq = tid % G::C4O, pg = tid / G::C4O;
-    const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
-    // persistent accumulators (flushed once per workgroup)
-    float4 gw2[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) gw2[t] = make_float4(0, 0, 0, 0);
-    float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
-    // per-lane partials of the producer's BN-backward sums, D layout: channel nt*16 + l15.
-    // fp64: sum(dy) cancels heavily and feeds c1 = mean(dy) of EVERY dz of the producer --
-    // fp32 partials here showed up as 0.3 % errors in depthwise weight gradients upstream.
-    // (kept in LDS, one fp64 atomic per lane / channel block / tile: as registers they cost 16
-    // VGPRs for the whole kernel and pushed the 64-channel variant into scratch)
-    for (int i = tid; i < 2 * CIN; i += BWD_THREADS) s_bst[i] = 0.0;
-    f32x4 gw1[G::MB * G::NB];   // dW1: this wave's interleaved 16x16 tiles
-#pragma unroll
-    for (int i = 0; i < G::MB * G::NB; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int w1_grp = wid % G::NGRP, w1_kslice = wid / G::NGRP;
-    const int w1_ci0 = (w1_grp / (G::NTO / G::NB)) * 16 * G::MB;   // first ci / co of the wave's block
-    const int w1_co0 = (w1_grp % (G::NTO / G::NB)) * 16 * G::NB;
-
     // per-image tiling, or (PACKED) one tile grid over the packed canvas of all images (common.h)
     const int tiles_x = ((PACKED ? pk.CW : W) + TW - 1) / TW, tiles_y = ((PACKED ? pk.CH : H) + TH - 1) / TH;
     const int tiles_img = tiles_x * tiles_y;
@@ -334,13 +270,95 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         }
     };
 
-    int t = blockIdx.x;
+    // the first tile's global loads go out BEFORE the weights / coefficients are staged: the HBM
+    // latency of a cold start runs under the prologue
     using All = std::integral_constant<int, -1>;
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t, All{});
+
+    if constexpr (GEMM == 1) {
+        // W1 -> bf16 hi / lo planes in both orientations, 8 weights per thread and pass, every global
+        // load of a pass in flight at once, 16-byte LDS stores
+        static_assert(COUT * CIN == 8 * BWD_THREADS, "one 8-weight group per thread");
+        {
+            const int co = tid / (CIN / 8), c0 = (tid % (CIN / 8)) * 8;
+            const float4 a = *reinterpret_cast<const float4*>(d.w_pw + co * CIN + c0);
+            const float4 b = *reinterpret_cast<const float4*>(d.w_pw + co * CIN + c0 + 4);
+            const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const Split8 sp = split8(w8);
+            *reinterpret_cast<u32x4*>(s_w1h + co * G::WSB + c0) = sp.hi;
+            *reinterpret_cast<u32x4*>(s_w1l + co * G::WSB + c0) = sp.lo;
+            if (c0 == 0) s_b1[co] = d.b_pw[co];
+        }
+        {
+            const int ci = tid / (COUT / 8), o0 = (tid % (COUT / 8)) * 8;
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = d.w_pw[(o0 + j) * CIN + ci];
+            const Split8 sp = split8(w8);
+            *reinterpret_cast<u32x4*>(s_w1th + ci * G::WSTB + o0) = sp.hi;
+            *reinterpret_cast<u32x4*>(s_w1tl + ci * G::WSTB + o0) = sp.lo;
+        }
+    } else {
+        for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
+            const float w = d.w_pw[i];
+            s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
+            if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
+            s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
+        }
+    }
+    for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
+    for (int c = tid; c < COUT; c += BWD_THREADS) {
+        if (bn_out) {
+            const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
+            s_co[c] = k.mean; s_co[COUT + c] = k.invstd; s_co[2 * COUT + c] = k.k1;
+            s_co[3 * COUT + c] = k.c1; s_co[4 * COUT + c] = k.c2;
+            s_co[5 * COUT + c] = k.mean_lo; s_co[6 * COUT + c] = k.c1_lo;
+        } else {
+            s_co[c] = 0.f; s_co[COUT + c] = 0.f;
+            s_co[2 * COUT + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
+            s_co[3 * COUT + c] = 0.f; s_co[4 * COUT + c] = 0.f;
+            s_co[5 * COUT + c] = 0.f; s_co[6 * COUT + c] = 0.f;
+        }
+    }
+    for (int c = tid; c < CIN; c += BWD_THREADS) {
+        if (bn_in) {
+            const BNCoef k = bn_coef(d.in_bn, CIN, c);
+            s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
+            s_ci[3 * CIN + c] = k.invstd; s_ci[4 * CIN + c] = k.mean_lo;
+        } else {
+            s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f; s_ci[3 * CIN + c] = 1.f;
+            s_ci[4 * CIN + c] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-thread constants ---------------------------------------------------------------
+    // VALU phase: channel quad cq, pixel column vtx, rows vr0..vr0+PPT-1
+    const int cq = tid % G::C4O, pg = tid / G::C4O;
+    const int vtx = pg % TW, vr0 = (pg / TW) * G::PPT;
+    // persistent accumulators (flushed once per workgroup)
+    float4 gw2[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gw2[t] = make_float4(0, 0, 0, 0);
+    float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
+    // per-lane partials of the producer's BN-backward sums, D layout: channel nt*16 + l15.
+    // fp64: sum(dy) cancels heavily and feeds c1 = mean(dy) of EVERY dz of the producer --
+    // fp32 partials here showed up as 0.3 % errors in depthwise weight gradients upstream.
+    // (kept in LDS, one fp64 atomic per lane / channel block / tile: as registers they cost 16
+    // VGPRs for the whole kernel and pushed the 64-channel variant into scratch)
+    for (int i = tid; i < 2 * CIN; i += BWD_THREADS) s_bst[i] = 0.0;
+    f32x4 gw1[G::MB * G::NB];   // dW1: this wave's interleaved 16x16 tiles
+#pragma unroll
+    for (int i = 0; i < G::MB * G::NB; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w1_grp = wid % G::NGRP, w1_kslice = wid / G::NGRP;
+    const int w1_ci0 = (w1_grp / (G::NTO / G::NB)) * 16 * G::MB;   // first ci / co of the wave's block
+    const int w1_co0 = (w1_grp % (G::NTO / G::NB)) * 16 * G::NB;
+
     // next tile's loads in four pieces (measured: -8 % on 16->16 at 160x160, -6 % on 16->64, +2 % on the
     // 64->16 heads, which keep the single issue)
     constexpr bool SPREAD = DP_BWD_PF_SPREAD && (GEMM == 1 || DP_BWD_PF_SPREAD_ALL || COUT >= 32 || CIN == 16);
     const bool pf_on = !(abl & 32);
-    if (t < ntiles) issue(t, All{});
 #ifdef DP_BWD_PROF
     const bool prof_on = (unsigned long long)d.prof >= 4096ull;
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
