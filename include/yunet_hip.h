@@ -17,6 +17,7 @@
 #ifndef YUNET_HIP_H
 #define YUNET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -240,9 +241,21 @@ int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
  * YuNet_Head.get_bboxes (mmdet/models/dense_heads/yunet_head.py:290-416): priors, sigmoid scores
  * (cls * obj) >= score_thr, _bbox_decode, then mmcv.ops.batched_nms for the single face class =
  * greedy NMS (IoU with offset 0, suppress when IoU > iou_thr), survivors in descending score.
- *  flat [N,P,16] raw head outputs of an eval-mode forward; P <= 16384.
+ *  flat [N,P,16] raw head outputs of an eval-mode forward; any P (candidates above the threshold
+ *  are compacted first; up to 16384 of them sort in LDS, more in the scratch -- an origin-size
+ *  WIDER image of 1024x1024 has P = 21504, tools/test_widerface.py --mode 2).
  *  dets [N,max_out,5] = x1 y1 x2 y2 score; kps [N,max_out,10] decoded landmarks or NULL
- *  (_kps_decode, yunet_head.py:388-393); count [N]; scratch >= N*P*16 bytes. */
+ *  (_kps_decode, yunet_head.py:388-393); count [N]; scratch >= yunet_detect_scratch_bytes(N, P). */
+size_t yunet_detect_scratch_bytes(int N, int P);
+/* mmcv.ops.batched_nms for ONE class on explicit candidates (the merge step of test-time
+ * augmentation, mmdet/models/dense_heads/dense_test_mixins.py:89-103): per set n the first
+ * counts[n] (or all K when counts == NULL) rows of boxes [N,K,4] / scores [N,K] with
+ * score >= score_thr, greedy NMS in descending score (ties: lower index first).
+ * dets [N,max_out,5], keep [N,max_out] (indices into the set, or NULL), count [N];
+ * scratch >= yunet_detect_scratch_bytes(N, K). */
+int yunet_nms(const float* boxes, const float* scores, const int32_t* counts, int N, int K,
+              float score_thr, float iou_thr, int max_out, float* dets, int32_t* keep,
+              int32_t* count, void* scratch, void* stream);
 int yunet_detect(const float* flat, const YunetLevels* lv, int N, int P, float score_thr,
                  float iou_thr, int max_out, float* dets, float* kps, int32_t* count, void* scratch,
                  void* stream);

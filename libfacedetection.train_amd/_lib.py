@@ -88,6 +88,8 @@ _SIGNATURES = {
     'yunet_reduce_partials_batch': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'yunet_detect': (C.c_int, [C.c_void_p, C.POINTER(YunetLevels), C.c_int, C.c_int, C.c_float, C.c_float,
                               C.c_int] + [C.c_void_p] * 5),
+    'yunet_detect_scratch_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'yunet_nms': (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 5),
     'yunet_aug_decide': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetAugCfg), C.c_uint32, C.c_int] +
                          [C.c_void_p] * 5),
     'yunet_aug_pixels': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetAugCfg), C.c_int, C.c_void_p, C.c_void_p]),

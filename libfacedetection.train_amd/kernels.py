@@ -239,12 +239,28 @@ def detect(flat, sizes, strides, score_thr=0.02, iou_thr=0.45, max_out=None, wit
     dets = torch.empty(n, max_out, 5, device=dev, dtype=torch.float32)
     kps = torch.empty(n, max_out, 10, device=dev, dtype=torch.float32) if with_kps else None
     count = torch.empty(n, device=dev, dtype=torch.int32)
-    scratch = torch.empty(n, p, 4, device=dev, dtype=torch.float32)
+    scratch = torch.empty(int(L.load().yunet_detect_scratch_bytes(n, p)), device=dev, dtype=torch.uint8)
     lv = make_levels(sizes, strides)
     L.check(L.load().yunet_detect(_p(flat), C.byref(lv), n, p, float(score_thr), float(iou_thr), max_out,
                                   _p(dets), _p(kps) if with_kps else None, _p(count), _p(scratch), _stream()),
             'yunet_detect')
     return dets, kps, count
+
+
+def nms(boxes, scores, iou_thr=0.45, score_thr=float('-inf'), max_out=None, counts=None):
+    """Greedy single-class NMS of explicit candidates: boxes [N,K,4], scores [N,K] (fp32 CUDA),
+    optional counts [N] int32 -> (dets [N,max_out,5], keep [N,max_out] int32, count [N])."""
+    _chk_f32(boxes, scores)
+    n, k = scores.shape
+    max_out = k if max_out is None or max_out < 0 else int(max_out)
+    dev = boxes.device
+    dets = torch.empty(n, max_out, 5, device=dev, dtype=torch.float32)
+    keep = torch.empty(n, max_out, device=dev, dtype=torch.int32)
+    count = torch.empty(n, device=dev, dtype=torch.int32)
+    scratch = torch.empty(int(L.load().yunet_detect_scratch_bytes(n, k)), device=dev, dtype=torch.uint8)
+    L.check(L.load().yunet_nms(_p(boxes), _p(scores), _p(counts), n, k, float(score_thr), float(iou_thr),
+                               max_out, _p(dets), _p(keep), _p(count), _p(scratch), _stream()), 'yunet_nms')
+    return dets, keep, count
 
 
 def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.1,

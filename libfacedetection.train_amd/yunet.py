@@ -37,6 +37,24 @@ class _LogRecord:
         return self.vals
 
 
+def bbox_mapping_back(bboxes, meta):
+    """Boxes of one test-time view -> original image coordinates
+    (mmdet/core/bbox/transforms.py:22-48, 63-72): un-flip with the view's img_shape, then divide
+    by its scale_factor."""
+    b = bboxes.clone()
+    if meta.get('flip', False):
+        direction = meta.get('flip_direction', 'horizontal')
+        h, w = meta['img_shape'][:2]
+        if direction not in ('horizontal', 'vertical', 'diagonal'):
+            raise ValueError(f'flip_direction {direction!r}')
+        if direction in ('horizontal', 'diagonal'):
+            b[:, 0], b[:, 2] = w - bboxes[:, 2], w - bboxes[:, 0]
+        if direction in ('vertical', 'diagonal'):
+            b[:, 1], b[:, 3] = h - bboxes[:, 3], h - bboxes[:, 1]
+    sf = torch.as_tensor(meta['scale_factor'], dtype=b.dtype, device=b.device).reshape(-1)
+    return b / (sf if sf.numel() == 4 else sf[:1])
+
+
 class LazyScalar:
     """A logged loss value that is copied to the host asynchronously and only waited for
     when somebody reads it (the reference calls .item() five times per iteration,
@@ -141,12 +159,58 @@ class YuNet(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     def forward_test(self, imgs, img_metas, **kwargs):
-        """mmdet/models/detectors/base.py:132-167: lists of length 1 (no test-time augmentation)."""
+        """mmdet/models/detectors/base.py:132-167: one augmentation -> simple_test, several
+        (MultiScaleFlipAug) -> aug_test."""
         if isinstance(imgs, (list, tuple)):
             if len(imgs) != 1:
-                raise NotImplementedError('aug_test (multi-scale / flip testing) is not built')
+                return self.aug_test(imgs, img_metas, **kwargs)
             imgs, img_metas = imgs[0], img_metas[0]
         return self.simple_test(imgs, img_metas, **kwargs)
+
+    @torch.no_grad()
+    def aug_test(self, imgs, img_metas, rescale=False):
+        """Test-time augmentation (mmdet/models/detectors/single_stage.py:135-157 ->
+        dense_test_mixins.py:41-114): every augmented view (scale and / or flip) of ONE image is
+        run through the eval forward, its candidates (score >= score_thr, decoded, no NMS) are
+        mapped back to the original image (bbox_mapping_back: un-flip with the view's img_shape,
+        divide by its scale_factor), the union is suppressed once (batched_nms) and cut to
+        max_per_img.  rescale=False multiplies the result by the first view's scale_factor.
+
+        Note on the reference: YuNet_Head.get_bboxes accepts with_nms but ignores it
+        (yunet_head.py:298, 410-415), so its mixin path hands already-suppressed [n,5] tensors to
+        bbox_mapping_back, whose view(-1, 4) then fails; this implements the behaviour the mixin
+        documents (with_nms=False per view)."""
+        if self.training:
+            raise RuntimeError('aug_test requires model.eval()')
+        cfg = self.test_cfg
+        if cfg is None:
+            raise ValueError('test_cfg (score_thr, nms.iou_threshold, max_per_img) is required')
+        from . import kernels as K
+        nms_cfg = cfg.get('nms', dict(type='nms', iou_threshold=0.45))
+        boxes, scores = [], []
+        for img, metas in zip(imgs, img_metas):
+            if img.shape[0] != 1:
+                raise ValueError('aug_test: one image per view (samples_per_gpu=1, as in the reference)')
+            if not img.is_cuda:
+                raise RuntimeError('YuNet.aug_test needs CUDA (ROCm) tensors: HIP kernels only, no CPU fallback')
+            eng = self._ensure_engine(img.device)
+            flat = eng.forward_eval(img.float().contiguous())
+            dets, _, cnt = K.detect(flat, eng.plan.sizes, self.bbox_head.strides, cfg.get('score_thr', 0.02),
+                                    iou_thr=2.0, with_kps=False)          # IoU <= 1: no suppression
+            d = dets[0, :int(cnt[0])]
+            b = bbox_mapping_back(d[:, :4], metas[0])
+            boxes.append(b)
+            scores.append(d[:, 4])
+        boxes, scores = torch.cat(boxes), torch.cat(scores)
+        if boxes.shape[0] == 0:
+            return [[torch.zeros(0, 5).numpy()]]
+        dets, _, cnt = K.nms(boxes[None].contiguous(), scores[None].contiguous(),
+                             nms_cfg.get('iou_threshold', 0.45), max_out=cfg.get('max_per_img', -1))
+        out = dets[0, :int(cnt[0])].clone()
+        if not rescale:
+            sf0 = torch.as_tensor(img_metas[0][0]['scale_factor'], dtype=torch.float32, device=out.device).reshape(-1)
+            out[:, :4] *= (sf0 if sf0.numel() == 4 else sf0[:1])
+        return [[out.cpu().numpy()]]
 
     @torch.no_grad()
     def simple_test(self, img, img_metas, rescale=False, with_landmarks=False):

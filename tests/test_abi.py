@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, 'include', 'yunet_hip.h')
 def declared_functions():
     txt = open(HEADER).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(yunet_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|size_t)\s+(yunet_\w+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():

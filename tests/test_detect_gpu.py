@@ -97,10 +97,13 @@ def exact_heads(n, P, seed):
     return flat
 
 
-@pytest.mark.parametrize('h,n,seed', [(160, 6, 1), (320, 3, 2), (640, 2, 3)])
+@pytest.mark.parametrize('h,n,seed', [(160, 6, 1), (320, 3, 2), (640, 2, 3), (1024, 2, 4), (1280, 1, 5)])
 def test_detect_kernel_vs_oracle_exact_geometry(h, n, seed):
     """Thousands of candidates per image with heavy overlap (K exceeds the LDS box cache at 640):
-    the survivors, their order and their boxes must be identical to the oracle's."""
+    the survivors, their order and their boxes must be identical to the oracle's.
+    1024: P = 21504 > 16384 priors (origin-size WIDER images, tools/test_widerface.py --mode 2) with
+    ~16.1 k candidates -- compacted through the scratch, sorted in LDS; 1280: P = 33600 with ~25 k
+    candidates -- more than the LDS holds, sorted in the global scratch."""
     sizes = C.featmap_sizes(h, h)
     P = sum(a * b for a, b in sizes)
     flat = exact_heads(n, P, seed)
@@ -158,12 +161,11 @@ def test_detect_edge_cases():
     dets2, _, cnt2 = _run_detect(flat, h, h, max_out=3)
     assert int(cnt2[0]) == min(3, int(cnt[0]))
     assert torch.equal(dets2[0, :int(cnt2[0])], dets[0, :int(cnt2[0])])
-    # P larger than the kernel's key array is rejected, like any unsupported shape
+    # a level table that does not add up to P is rejected, like any unsupported shape
     import yunet_amd.kernels as k
     from yunet_amd._lib import YunetHipError
     with pytest.raises(YunetHipError):
-        k.detect(torch.zeros(1, 1280 * 1280 // 64 + 1280 * 1280 // 256 + 1280 * 1280 // 1024, 16, device=DEV),
-                 C.featmap_sizes(1280, 1280), [8, 16, 32])
+        k.detect(torch.zeros(1, 777, 16, device=DEV), C.featmap_sizes(160, 160), [8, 16, 32])
 
 
 def test_detect_full_batch_properties():
@@ -182,3 +184,52 @@ def test_detect_full_batch_properties():
             assert float(D.nms_iou(d[j, :4], d[j + 1:, :4]).max()) <= 0.45 + 1e-6
         ref = D.get_bboxes(flat[i:i + 1], C.featmap_sizes(h, h), [8, 16, 32], 0.02, 0.45)[0][0]
         assert torch.equal(d[:, :4], ref[:, :4])
+
+
+def test_nms_kernel_vs_oracle_and_counts():
+    """yunet_nms (explicit boxes + scores, the merge step of aug_test) == the oracle's greedy NMS:
+    kept indices, order, boxes; per-set element counts; score threshold; max_out."""
+    import yunet_amd.kernels as k
+    g = torch.Generator().manual_seed(3)
+    n, K = 3, 3000
+    xy = torch.randint(0, 160, (n, K, 2), generator=g).float()
+    wh = torch.randint(4, 40, (n, K, 2), generator=g).float()
+    boxes = torch.cat([xy, xy + wh], -1).contiguous()
+    scores = (torch.stack([torch.randperm(K, generator=g) for _ in range(n)]).float() + 1) / (K + 1)
+    counts = torch.tensor([K, 1234, 1], dtype=torch.int32)
+    dets, keep, cnt = k.nms(boxes.to(DEV), scores.to(DEV), 0.45, counts=counts.to(DEV))
+    torch.cuda.synchronize()
+    for i in range(n):
+        c = int(counts[i])
+        ref = D.nms_greedy(boxes[i, :c], scores[i, :c], 0.45)
+        m = int(cnt[i])
+        assert m == len(ref)
+        assert torch.equal(keep[i, :m].cpu().long(), ref)
+        assert torch.equal(dets[i, :m, :4].cpu(), boxes[i, ref]) and torch.equal(dets[i, :m, 4].cpu(), scores[i, ref])
+    # threshold + max_out
+    dets, keep, cnt = k.nms(boxes[:1].to(DEV), scores[:1].to(DEV), 0.45, score_thr=0.5, max_out=7)
+    sel = torch.nonzero(scores[0] >= 0.5).squeeze(1)
+    ref = sel[D.nms_greedy(boxes[0, sel], scores[0, sel], 0.45)][:7]
+    assert int(cnt[0]) == 7 and torch.equal(keep[0, :7].cpu().long(), ref)
+    # iou_thr >= 1: nothing suppressed, everything out in score order
+    dets, keep, cnt = k.nms(boxes[:1].to(DEV), scores[:1].to(DEV), 2.0)
+    assert int(cnt[0]) == K and torch.equal(keep[0].cpu().long(), torch.sort(scores[0], descending=True).indices)
+
+
+def test_aug_test_single_view_twice_equals_simple_test():
+    """Two identical views: the union holds every candidate twice with equal scores; one NMS over
+    the union keeps the first copy and suppresses the second (IoU 1), i.e. exactly simple_test."""
+    arch, sd = D.make_state('n', 5, size=160)
+    model = build_model('n', sd)
+    img = D.structured_images(1, 320, 9).to(DEV)
+    meta = dict(img_shape=(320, 320, 3), scale_factor=[1.0, 1.0, 1.0, 1.0], flip=False, flip_direction='horizontal')
+    one = model.simple_test(img, [meta])[0][0]
+    two = model.forward_test([img, img], [[meta], [dict(meta)]])[0][0]
+    assert one.shape[0] > 5 and np.array_equal(one, two)
+    # a second view at half the resolution maps back into the same frame: boxes stay inside it
+    small = torch.nn.functional.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+    m2 = dict(img_shape=(160, 160, 3), scale_factor=[0.5, 0.5, 0.5, 0.5], flip=True, flip_direction='horizontal')
+    both = model.forward_test([img, small.contiguous()], [[meta], [m2]], rescale=True)[0][0]
+    assert both.shape[1] == 5 and both.shape[0] >= 1
+    assert np.all(np.diff(both[:, 4]) <= 0), 'descending score'
+    assert np.isfinite(both).all() and (both[:, 2] > both[:, 0]).all() and (both[:, 3] > both[:, 1]).all()

@@ -221,3 +221,33 @@ def test_bench_byte_model_matches_survey_figures():
     # the committed PMC table is found and keyed by the names bench.py prints
     traffic, src = bench.pmc_traffic('dp_bwd_kernel<64,64,8,16,false>')
     assert traffic is not None and traffic > 1e8 and src.endswith('_pmc_traffic.json')
+
+
+def test_bbox_mapping_back_matches_reference():
+    """aug_test's un-flip + un-scale == mmdet/core/bbox/transforms.py:bbox_mapping_back."""
+    import importlib.util
+    import torch
+    from yunet_amd.yunet import bbox_mapping_back
+    g = torch.Generator().manual_seed(0)
+    b = torch.rand(7, 4, generator=g) * 300
+    b[:, 2:] += b[:, :2]
+    ref_path = '/root/reference/mmdet/core/bbox/transforms.py'
+    ref = None
+    if os.path.exists(ref_path):
+        spec = importlib.util.spec_from_file_location('ref_bbox_transforms', ref_path)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+    for flip, direction in ((False, 'horizontal'), (True, 'horizontal'), (True, 'vertical'), (True, 'diagonal')):
+        for sf in ([0.5, 0.5, 0.5, 0.5], [1.25, 0.8, 1.25, 0.8]):
+            meta = dict(img_shape=(480, 640, 3), scale_factor=sf, flip=flip, flip_direction=direction)
+            got = bbox_mapping_back(b, meta)
+            # definition: flip about the view's width / height, then divide by the scale factor
+            want = b.clone()
+            if flip and direction in ('horizontal', 'diagonal'):
+                want[:, 0], want[:, 2] = 640 - b[:, 2], 640 - b[:, 0]
+            if flip and direction in ('vertical', 'diagonal'):
+                want[:, 1], want[:, 3] = 480 - b[:, 3], 480 - b[:, 1]
+            want = want / torch.tensor(sf)
+            assert torch.equal(got, want)
+            if ref is not None:
+                assert torch.equal(got, ref.bbox_mapping_back(b, (480, 640, 3), sf, flip, direction))
