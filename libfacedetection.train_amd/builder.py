@@ -9,6 +9,7 @@ BBOX_SAMPLERS = Registry('bbox_sampler')
 PRIOR_GENERATORS = Registry('Generator for anchors and points')
 ANCHOR_GENERATORS = PRIOR_GENERATORS
 PIPELINES = Registry('pipeline')          # mmdet/datasets/builder.py:23
+DATASETS = Registry('dataset')            # mmdet/datasets/builder.py:22
 
 
 def build_backbone(cfg):
@@ -41,3 +42,8 @@ def build_sampler(cfg, **default_args):
 
 def build_prior_generator(cfg, default_args=None):
     return build_from_cfg(cfg, PRIOR_GENERATORS, default_args)
+
+
+def build_dataset(cfg, default_args=None):
+    """mmdet/datasets/builder.py:59 for the dataset types this package registers."""
+    return build_from_cfg(cfg, DATASETS, default_args)

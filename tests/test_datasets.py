@@ -1,0 +1,119 @@
+"""CPU: the labelv2 reader (datasets.RetinaFaceDataset) against the UNMODIFIED reference class
+(mmdet/datasets/retinaface.py executed under a two-module package skeleton: builder.DATASETS and
+custom.CustomDataset are the only names it imports) on the reference's own
+data/widerface/labelv2/val/labelv2.txt, plus format edge cases on a hand-written file."""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+REF = '/root/reference'
+LABELS = os.path.join(REF, 'data', 'widerface', 'labelv2', 'val', 'labelv2.txt')
+
+
+def reference_class():
+    pkg = types.ModuleType('refds')
+    pkg.__path__ = []
+    b = types.ModuleType('refds.builder')
+
+    class _Reg:
+        def register_module(self):
+            return lambda c: c
+    b.DATASETS = _Reg()
+    c = types.ModuleType('refds.custom')
+    c.CustomDataset = object
+    pc = types.ModuleType('pycocotools')
+    pc.__version__ = '12.0.2'
+    sys.modules.update({'refds': pkg, 'refds.builder': b, 'refds.custom': c})
+    sys.modules.setdefault('pycocotools', pc)
+    spec = importlib.util.spec_from_file_location('refds.retinaface',
+                                                  os.path.join(REF, 'mmdet', 'datasets', 'retinaface.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.RetinaFaceDataset
+
+
+def _ref_instance(ann_file, min_size, test_mode):
+    cls = reference_class()
+    o = object.__new__(cls)
+    o.NK, o.cat2label, o.min_size, o.test_mode = 5, {'FG': 0}, min_size, test_mode
+    o.data_infos = o.load_annotations(ann_file)
+    return o
+
+
+@pytest.mark.skipif(not os.path.exists(LABELS), reason='reference tree not present')
+@pytest.mark.parametrize('test_mode', [True])
+def test_labelv2_val_matches_reference(test_mode):
+    import yunet_amd
+    ds = yunet_amd.build_dataset(dict(type='RetinaFaceDataset', ann_file=LABELS, img_prefix='', pipeline=[],
+                                      test_mode=test_mode))
+    ref = _ref_instance(LABELS, None, test_mode)
+    assert len(ds) == len(ref.data_infos) == 3226
+    for i in range(0, len(ds), 7):
+        a, b = ds.data_infos[i], ref.data_infos[i]
+        assert (a['filename'], a['width'], a['height']) == (b['filename'], b['width'], b['height'])
+        x, y = ds.get_ann_info(i), ref.get_ann_info(i)
+        assert set(x) == set(y)
+        for k in x:
+            assert x[k].dtype == y[k].dtype and x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), (i, k)
+
+
+TRAIN_TXT = """# 0--Parade/a.jpg 1024 678
+10 20 110 140 30.5 40.5 0.0 60 41 0.0 45 70 0.0 35 90 1.0 58 92 1.0 0.87
+200 210 204 215 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 -1 0.3
+300 310 340 350 1
+400 410 440 450 0
+# 1--Handshaking/b.jpg 500 700
+1 2 3 4 -1 -1 -1 5 6 0.0 -1 -1 -1 -1 -1 -1 -1 -1 -1 0.5
+# 2--Empty/c.jpg 10 10
+# 0--Parade/a.jpg 1024 678
+7 8 90 100 0
+"""
+
+
+def test_labelv2_train_format_edge_cases(tmp_path):
+    """Landmark flags, all -1 rows, ignore flags, min_size, empty images, a repeated header."""
+    import yunet_amd.datasets as DS
+    f = tmp_path / 'labelv2.txt'
+    f.write_text(TRAIN_TXT)
+    infos = DS.load_labelv2(str(f), min_size=8)
+    assert [it['filename'] for it in infos] == ['0--Parade/a.jpg', '1--Handshaking/b.jpg']   # empty image dropped
+    a = DS.ann_info(infos[0])                       # the repeated header replaced the first block
+    assert a['bboxes'].tolist() == [[7, 8, 90, 100]] and a['bboxes_ignore'].shape == (0, 4)
+    b = DS.ann_info(infos[1])
+    assert b['bboxes'].shape == (0, 4) and b['bboxes_ignore'].tolist() == [[1, 2, 3, 4]]    # 2 px < min_size
+    one = DS.parse_ann_line('10 20 110 140 30.5 40.5 0.0 60 41 0.0 45 70 0.0 35 90 1.0 58 92 1.0 0.87')
+    assert one['kps'][:, 2].tolist() == [1.0] * 5 and not one['ignore']
+    none = DS.parse_ann_line('200 210 204 215 ' + '-1 ' * 15 + '0.3')
+    assert none['kps'][:, 2].tolist() == [0.0] * 5
+    assert DS.parse_ann_line('300 310 340 350 1')['ignore'] and not DS.parse_ann_line('300 310 340 350 0')['ignore']
+    with pytest.raises(AssertionError):
+        DS.parse_ann_line('1 2 3 4')                 # bare boxes are test annotations
+    assert DS.parse_ann_line('1 2 3 4', test_mode=True)['bbox'].tolist() == [1, 2, 3, 4]
+    if os.path.exists(LABELS):
+        ref = _ref_instance(str(f), 8, False)
+        assert [it['filename'] for it in ref.data_infos] == [it['filename'] for it in infos]
+        for i in range(len(infos)):
+            x, y = DS.ann_info(infos[i]), ref.get_ann_info(i)
+            for k in x:
+                assert np.array_equal(x[k], y[k]) and x[k].dtype == y[k].dtype, (i, k)
+
+
+def test_dataset_decodes_to_device_pipeline_sources(tmp_path):
+    """__getitem__ : PIL decode -> uint8 BGR HWC + annotations, the input contract of SourceBatch."""
+    from PIL import Image
+    import yunet_amd
+    rng = np.random.default_rng(0)
+    os.makedirs(tmp_path / 'img' / '0--Parade')
+    rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / 'img' / '0--Parade' / 'a.png')
+    (tmp_path / 'l.txt').write_text('# 0--Parade/a.png 64 48\n4 5 30 40 ' + '10 10 1.0 ' * 5 + '0.9\n')
+    ds = yunet_amd.build_dataset(dict(type='RetinaFaceDataset', ann_file=str(tmp_path / 'l.txt'),
+                                      img_prefix=str(tmp_path / 'img'), pipeline=[]))
+    s = ds[0]
+    assert s['img'].dtype == np.uint8 and s['img'].shape == (48, 64, 3)
+    assert np.array_equal(s['img'][:, :, ::-1], rgb)           # BGR, like cv2.imread
+    assert s['gt_bboxes'].shape == (1, 4) and s['gt_keypointss'].shape == (1, 5, 3)
