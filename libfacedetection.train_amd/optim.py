@@ -20,6 +20,7 @@ class FusedSGD:
         self._lr_dev = None
         self._lr_val = None
         self._steps = 0
+        self.grad_scale = 1.0      # multiplies the gradient inside the update kernel (loss-scale removal)
 
     def _bind(self):
         eng = self.model.engine
@@ -52,7 +53,7 @@ class FusedSGD:
             self._lr_dev.fill_(float(g['lr']))
             self._lr_val = g['lr']
         K.sgd_step(eng.params.data, eng.params.grad, self._buf, self._lr_dev, g['momentum'],
-                   g['weight_decay'], 1.0, first=(self._steps == 0))
+                   g['weight_decay'], float(self.grad_scale), first=(self._steps == 0))
         self._steps += 1
 
     def state_dict(self):

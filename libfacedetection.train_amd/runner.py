@@ -108,55 +108,354 @@ def load_checkpoint(model, path, optimizer=None, strict=True):
     return ck.get('meta', {})
 
 
+# ================================================================================ hooks / runner
+PRIORITY = dict(HIGHEST=0, VERY_HIGH=10, HIGH=30, ABOVE_NORMAL=40, NORMAL=50, BELOW_NORMAL=60, LOW=70,
+                VERY_LOW=90, LOWEST=100)
+
+
+class Hook:
+    """mmcv.runner.Hook: the stage methods an EpochBasedRunner calls."""
+    stages = ('before_run', 'before_train_epoch', 'before_train_iter', 'after_train_iter',
+              'after_train_epoch', 'after_run')
+
+    def before_run(self, runner): pass                    # noqa: E704
+    def after_run(self, runner): pass                     # noqa: E704
+    def before_epoch(self, runner): pass                  # noqa: E704
+    def after_epoch(self, runner): pass                   # noqa: E704
+    def before_iter(self, runner): pass                   # noqa: E704
+    def after_iter(self, runner): pass                    # noqa: E704
+
+    def before_train_epoch(self, runner):
+        self.before_epoch(runner)
+
+    def after_train_epoch(self, runner):
+        self.after_epoch(runner)
+
+    def before_train_iter(self, runner):
+        self.before_iter(runner)
+
+    def after_train_iter(self, runner):
+        self.after_iter(runner)
+
+    def every_n_iters(self, runner, n):
+        return (runner.iter + 1) % n == 0 if n > 0 else False
+
+    def every_n_epochs(self, runner, n):
+        return (runner.epoch + 1) % n == 0 if n > 0 else False
+
+
+class StepLrUpdaterHook(Hook):
+    """lr_config = dict(policy='step', ...) (configs/yunet_n.py:4-10): sets the lr of every param group
+    before each iteration (by-epoch steps, by-iteration linear warm-up)."""
+
+    def __init__(self, base_lr=None, **cfg):
+        self.cfg, self.base_lr, self.sched = cfg, base_lr, None
+
+    def before_run(self, runner):
+        base = self.base_lr if self.base_lr is not None else runner.optimizer.param_groups[0].get(
+            'initial_lr', runner.optimizer.param_groups[0]['lr'])
+        self.sched = StepLrWarmup(base, **self.cfg)
+
+    def before_train_iter(self, runner):
+        lr = self.sched.lr_at(runner.epoch, runner.iter)
+        for g in runner.optimizer.param_groups:
+            g['lr'] = lr
+
+
+class OptimizerHook(Hook):
+    """optimizer_config = dict(grad_clip=None): zero_grad -> backward -> step (mmcv OptimizerHook)."""
+
+    def __init__(self, grad_clip=None, **_):
+        self.grad_clip = grad_clip
+
+    def after_train_iter(self, runner):
+        runner.optimizer.zero_grad()
+        runner.outputs['loss'].backward()
+        if self.grad_clip is not None:
+            params = [p for p in runner.model.parameters() if p.requires_grad and p.grad is not None]
+            torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)
+        runner.optimizer.step()
+
+
+class Fp16OptimizerHook(OptimizerHook):
+    """cfg.fp16 = dict(loss_scale=512.) (mmdet/apis/train.py:181-185 -> mmcv Fp16OptimizerHook).
+    The reference's mixed precision is fp16 storage with loss scaling.  On MI355X the reduced
+    precision mode of this path is bf16 activation storage + bf16 matrix instructions in forward with
+    fp32 gradients and master weights (BASELINE.json configs[2]); bf16 keeps fp32's exponent range,
+    so the loss scale is applied and removed exactly (a power of two) and only the overflow check of
+    `loss_scale='dynamic'` ever changes anything: a step with non-finite gradients is skipped and the
+    scale halves, 2000 clean steps double it (mmcv LossScaler defaults)."""
+
+    def __init__(self, grad_clip=None, loss_scale=512., distributed=True, **_):
+        super().__init__(grad_clip)
+        self.dynamic = loss_scale == 'dynamic' or isinstance(loss_scale, dict)
+        init = 2. ** 16 if loss_scale == 'dynamic' else (loss_scale.get('init_scale', 2. ** 16)
+                                                          if isinstance(loss_scale, dict) else float(loss_scale))
+        self.scale, self.growth_interval, self._good = float(init), 2000, 0
+
+    def before_run(self, runner):
+        target = runner.model.module if hasattr(runner.model, 'module') else runner.model
+        target.set_precision('bf16')
+
+    def after_train_iter(self, runner):
+        opt = runner.optimizer
+        opt.zero_grad()
+        (runner.outputs['loss'] * self.scale).backward()
+        target = runner.model.module if hasattr(runner.model, 'module') else runner.model
+        grad = target.engine.params.grad
+        if self.dynamic and not bool(torch.isfinite(grad).all()):
+            self.scale = max(self.scale / 2.0, 1.0)
+            self._good = 0
+            return                                             # skip the step, like LossScaler
+        if hasattr(opt, 'grad_scale'):
+            opt.grad_scale = 1.0 / self.scale                  # FusedSGD: folded into the update kernel
+        else:
+            grad.mul_(1.0 / self.scale)
+        if self.grad_clip is not None:
+            params = [p for p in runner.model.parameters() if p.requires_grad and p.grad is not None]
+            torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)
+        opt.step()
+        if self.dynamic:
+            self._good += 1
+            if self._good % self.growth_interval == 0:
+                self.scale *= 2.0
+
+
+class CheckpointHook(Hook):
+    """checkpoint_config = dict(interval=N) : epoch_{k}.pth + a `latest.pth` copy (rank 0)."""
+
+    def __init__(self, interval=1, by_epoch=True, max_keep_ckpts=-1, **_):
+        self.interval, self.by_epoch, self.max_keep = interval, by_epoch, max_keep_ckpts
+
+    def after_train_epoch(self, runner):
+        if runner.rank != 0 or not runner.work_dir or not self.every_n_epochs(runner, self.interval):
+            return
+        runner.save_checkpoint(runner.work_dir, f'epoch_{runner.epoch + 1}.pth')
+        if self.max_keep > 0:
+            old = runner.epoch + 1 - self.max_keep * self.interval
+            path = os.path.join(runner.work_dir, f'epoch_{old}.pth')
+            if old > 0 and os.path.exists(path):
+                os.remove(path)
+
+
+class LoggerHook(Hook):
+    def __init__(self, interval=50, by_epoch=True, **_):
+        self.interval, self.by_epoch = interval, by_epoch
+        self._t0 = None
+
+    def before_run(self, runner):
+        self._t0 = time.time()
+
+    def after_train_iter(self, runner):
+        if not self.every_n_iters(runner, self.interval):
+            return
+        # log_vars are lazily copied device scalars backed by a 256-row staging ring: freeze them
+        # into python floats when they are logged, never keep the lazy objects
+        lv = {k: float(v) for k, v in runner.outputs['log_vars'].items()}
+        dt = (time.time() - self._t0) / self.interval
+        self._t0 = time.time()
+        rec = dict(lv, iter=runner.iter + 1, epoch=runner.epoch + 1, lr=runner.current_lr()[0], time=dt)
+        if not runner.log_buffer or runner.log_buffer[-1]['iter'] != rec['iter']:
+            runner.log_buffer.append(rec)            # once per iteration, however many logger hooks
+        if runner.rank == 0:
+            self.log(runner, rec)
+
+    def log(self, runner, rec):
+        raise NotImplementedError
+
+
+class TextLoggerHook(LoggerHook):
+    def log(self, runner, rec):
+        keys = [k for k in rec if k not in ('iter', 'epoch', 'lr', 'time')]
+        runner.logger(f"Epoch [{rec['epoch']}][{rec['iter']}] lr: {rec['lr']:.3e}, time: {rec['time']:.4f}, " +
+                      ', '.join(f'{k}: {rec[k]:.4f}' for k in keys))
+
+
+class TensorboardLoggerHook(LoggerHook):
+    """configs/yunet_n.py:14-17.  Writes TensorBoard event files directly (tfevents record framing +
+    Event / Summary protobuf wire format, masked CRC-32C) -- no tensorboard package needed."""
+
+    def __init__(self, log_dir=None, interval=50, **kw):
+        super().__init__(interval, **kw)
+        self.log_dir, self.writer = log_dir, None
+
+    def before_run(self, runner):
+        super().before_run(runner)
+        if runner.rank == 0:
+            from .tb_events import EventWriter
+            d = self.log_dir or os.path.join(runner.work_dir or '.', 'tf_logs')
+            self.writer = EventWriter(d)
+
+    def log(self, runner, rec):
+        if self.writer is None:
+            return
+        for k, v in rec.items():
+            if k not in ('iter', 'epoch'):
+                self.writer.add_scalar(('train/' + k) if k != 'lr' else 'learning_rate', v, rec['iter'])
+        self.writer.flush()
+
+    def after_run(self, runner):
+        if self.writer is not None:
+            self.writer.close()
+
+
+HOOKS = dict(TextLoggerHook=TextLoggerHook, TensorboardLoggerHook=TensorboardLoggerHook,
+             CheckpointHook=CheckpointHook, OptimizerHook=OptimizerHook, Fp16OptimizerHook=Fp16OptimizerHook)
+
+
+class EpochBasedRunner:
+    """The slice of mmcv.runner.EpochBasedRunner the reference's train_detector drives
+    (mmdet/apis/train.py:169-246): register_training_hooks / register_hook / resume /
+    load_checkpoint / run, and per iteration  before_train_iter hooks -> model.train_step ->
+    after_train_iter hooks (OptimizerHook: zero_grad, backward, step)."""
+
+    def __init__(self, model, optimizer=None, work_dir=None, logger=print, meta=None, max_epochs=None,
+                 max_iters=None):
+        self.model, self.optimizer, self.work_dir, self.logger = model, optimizer, work_dir, logger
+        self.meta = dict(meta or {})
+        self.rank, self.world_size = get_dist_info()
+        self._max_epochs, self._max_iters = max_epochs, max_iters
+        self.epoch, self.iter, self.inner_iter = 0, 0, 0
+        self.hooks, self.outputs, self.log_buffer = [], None, []
+        self.data_source, self.device = None, 'cuda'
+
+    @property
+    def max_epochs(self):
+        return self._max_epochs
+
+    def current_lr(self):
+        return [g['lr'] for g in self.optimizer.param_groups]
+
+    def register_hook(self, hook, priority='NORMAL'):
+        hook.priority = PRIORITY[priority] if isinstance(priority, str) else int(priority)
+        pos = len(self.hooks)
+        while pos > 0 and self.hooks[pos - 1].priority > hook.priority:
+            pos -= 1
+        self.hooks.insert(pos, hook)
+
+    def register_training_hooks(self, lr_config, optimizer_config=None, checkpoint_config=None, log_config=None,
+                                momentum_config=None, custom_hooks_config=None):
+        if lr_config is not None:
+            cfg = dict(lr_config)
+            policy = cfg.pop('policy', 'step')
+            if policy != 'step':
+                raise NotImplementedError(f'lr policy {policy!r}: the reference configs use "step"')
+            self.register_hook(StepLrUpdaterHook(policy=policy, **cfg), 'VERY_HIGH')
+        if isinstance(optimizer_config, Hook):
+            self.register_hook(optimizer_config, 'ABOVE_NORMAL')
+        else:
+            oc = dict(optimizer_config or {})
+            self.register_hook(HOOKS[oc.pop('type', 'OptimizerHook')](**oc), 'ABOVE_NORMAL')
+        if checkpoint_config is not None:
+            self.register_hook(CheckpointHook(**checkpoint_config), 'NORMAL')
+        if log_config is not None:
+            for h in log_config.get('hooks', [dict(type='TextLoggerHook')]):
+                h = dict(h)
+                self.register_hook(HOOKS[h.pop('type')](interval=log_config.get('interval', 50), **h), 'VERY_LOW')
+        for h in custom_hooks_config or []:
+            h = dict(h)
+            prio = h.pop('priority', 'NORMAL')
+            self.register_hook(HOOKS[h.pop('type')](**h), prio)
+
+    def call_hook(self, stage):
+        for h in self.hooks:
+            getattr(h, stage)(self)
+
+    def save_checkpoint(self, out_dir, filename, create_latest=True):
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, filename)
+        save_checkpoint(self.model, self.optimizer, path, dict(self.meta, epoch=self.epoch + 1, iter=self.iter))
+        if create_latest:
+            import shutil
+            shutil.copyfile(path, os.path.join(out_dir, 'latest.pth'))
+
+    def load_checkpoint(self, path):
+        return load_checkpoint(self.model, path)
+
+    def resume(self, path):
+        m = load_checkpoint(self.model, path, self.optimizer)
+        self.epoch, self.iter = m.get('epoch', 0), m.get('iter', 0)
+        self.logger(f'resumed epoch {self.epoch}, iter {self.iter} from {path}')
+
+    def train(self, data_source):
+        self.model.train()
+        self.call_hook('before_train_epoch')
+        for i in range(data_source.iters_per_epoch):
+            self.inner_iter = i
+            self.call_hook('before_train_iter')
+            batch = data_source.batch(self.iter, self.device)
+            self.outputs = self.model.train_step(batch, self.optimizer)
+            self.call_hook('after_train_iter')
+            self.iter += 1
+            if self._max_iters is not None and self.iter >= self._max_iters:
+                return False
+        self.call_hook('after_train_epoch')
+        self.epoch += 1
+        return True
+
+    def run(self, data_sources, workflow=(('train', 1),), device='cuda'):
+        self.device = device
+        src = data_sources[0] if isinstance(data_sources, (list, tuple)) else data_sources
+        self.call_hook('before_run')
+        while self.epoch < self._max_epochs:
+            if not self.train(src):
+                break
+        self.call_hook('after_run')
+        return self.log_buffer
+
+
+def find_latest_checkpoint(path, suffix='pth'):
+    """mmdet/utils/misc.py:11-42: `latest.pth` if present, else the checkpoint with the largest
+    trailing number (epoch_12.pth, iter_5000.pth)."""
+    import glob
+    import warnings
+    if not os.path.exists(path):
+        warnings.warn('The path of checkpoints does not exist.')
+        return None
+    if os.path.exists(os.path.join(path, f'latest.{suffix}')):
+        return os.path.join(path, f'latest.{suffix}')
+    best, best_path = -1, None
+    for ck in glob.glob(os.path.join(path, f'*.{suffix}')):
+        try:
+            n = int(os.path.basename(ck).split('_')[-1].split('.')[0])
+        except ValueError:
+            continue
+        if n > best:
+            best, best_path = n, ck
+    if best_path is None:
+        warnings.warn('There are no checkpoints in the path.')
+    return best_path
+
+
 def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None,
                    meta=None, max_iters=None, device='cuda', log=print):
-    """mmdet/apis/train.py:117 surface.  Returns the logged history: one dict of python floats
-    per logging interval (every iteration for short runs with max_iters <= 64)."""
-    rank, world = get_dist_info()
+    """mmdet/apis/train.py:117-246 surface: DDP wrap, optimizer, EpochBasedRunner, fp16 / optimizer /
+    lr / checkpoint / logger hooks from the config, auto-resume / resume / load_from, run.
+    Returns the logged history (one dict of python floats per logging interval)."""
     model = model.to(device)
     model.train()
     if distributed:
         model = build_ddp(model, device, device_ids=[torch.cuda.current_device()],
                           broadcast_buffers=False)
     optimizer = build_optimizer(model, cfg.optimizer)
-    sched = StepLrWarmup(cfg.optimizer['lr'], **cfg.lr_config)
-    max_epochs = cfg.runner['max_epochs']
-    interval = cfg.log_config['interval'] if 'log_config' in cfg else 50
-    ck_interval = cfg.checkpoint_config['interval'] if 'checkpoint_config' in cfg else 0
-    work_dir = cfg.get('work_dir')
-    start_epoch, it = 0, 0
-    if cfg.get('resume_from'):
-        m = load_checkpoint(model, cfg.resume_from, optimizer)
-        start_epoch, it = m.get('epoch', 0), m.get('iter', 0)
+    runner = EpochBasedRunner(model, optimizer, cfg.get('work_dir'), log, meta,
+                              max_epochs=cfg.runner['max_epochs'], max_iters=max_iters)
+    fp16_cfg = cfg.get('fp16', None)
+    opt_cfg = dict(cfg.get('optimizer_config') or {})
+    if fp16_cfg is not None:
+        optimizer_config = Fp16OptimizerHook(**opt_cfg, **fp16_cfg, distributed=distributed)
+    else:
+        optimizer_config = opt_cfg
+    log_config = cfg.get('log_config')
+    if max_iters is not None and max_iters <= 64 and log_config is not None:
+        log_config = dict(log_config, interval=1)          # short smoke runs: log every iteration
+    runner.register_training_hooks(cfg.lr_config, optimizer_config, cfg.get('checkpoint_config'), log_config,
+                                   cfg.get('momentum_config'), cfg.get('custom_hooks'))
+    resume_from = cfg.get('resume_from')
+    if not resume_from and cfg.get('auto_resume') and cfg.get('work_dir'):
+        resume_from = find_latest_checkpoint(cfg.work_dir)
+    if resume_from:
+        runner.resume(resume_from)
     elif cfg.get('load_from'):
-        load_checkpoint(model, cfg.load_from)
-    history = []
-    t0 = time.time()
-    for epoch in range(start_epoch, max_epochs):
-        for _ in range(dataset.iters_per_epoch):
-            lr = sched.lr_at(epoch, it)
-            for g in optimizer.param_groups:
-                g['lr'] = lr
-            batch = dataset.batch(it, device)
-            out = model.train_step(batch, optimizer)
-            optimizer.zero_grad()
-            out['loss'].backward()
-            optimizer.step()
-            it += 1
-            if it % interval == 0 or (max_iters is not None and max_iters <= 64):
-                # log_vars are lazily copied device scalars backed by a 256-row staging ring:
-                # freeze them into python floats when they are logged, never keep the lazy objects
-                lv = {k: float(v) for k, v in out['log_vars'].items()}
-                history.append(dict(lv, iter=it, epoch=epoch + 1, lr=lr))
-            if rank == 0 and it % interval == 0:
-                dt = (time.time() - t0) / interval
-                t0 = time.time()
-                log(f'Epoch [{epoch + 1}][{it}] lr: {lr:.3e}, time: {dt:.4f}, ' +
-                    ', '.join(f'{k}: {v:.4f}' for k, v in lv.items()))
-            if max_iters is not None and it >= max_iters:
-                return history
-        if rank == 0 and work_dir and ck_interval and (epoch + 1) % ck_interval == 0:
-            os.makedirs(work_dir, exist_ok=True)
-            save_checkpoint(model, optimizer, os.path.join(work_dir, f'epoch_{epoch + 1}.pth'),
-                            dict(meta or {}, epoch=epoch + 1, iter=it))
-    return history
+        runner.load_checkpoint(cfg.load_from)
+    return runner.run([dataset], cfg.get('workflow', [('train', 1)]), device=device)

@@ -58,6 +58,8 @@ def main():
         './work_dirs', os.path.splitext(os.path.basename(args.config))[0])
     if args.resume_from:
         cfg['resume_from'] = args.resume_from
+    if args.auto_resume:                      # tools/train.py:118 -> mmdet/apis/train.py:236-240
+        cfg['auto_resume'] = True
     distributed = args.launcher != 'none'
     if distributed:
         init_dist(args.launcher, **cfg.get('dist_params', dict(backend='nccl')))
@@ -74,10 +76,15 @@ def main():
         ds = R.SyntheticWiderFace(samples_per_gpu=cfg.data.samples_per_gpu, rank=rank, **kw)
     elif dcfg.get('type') == 'SyntheticSourceImages':      # device-side reference pipeline
         ds = R.SyntheticSourceImages(samples_per_gpu=cfg.data.samples_per_gpu, rank=rank, seed=seed, **kw)
+    elif dcfg.get('type') == 'RetinaFaceDataset':          # labelv2 annotations + image files (PIL decode)
+        from yunet_amd.datasets import RetinaFaceSource
+        dataset = yunet_amd.build_dataset(dcfg)
+        ds = RetinaFaceSource(dataset, dcfg['pipeline'], samples_per_gpu=cfg.data.samples_per_gpu, rank=rank,
+                              world=world, seed=seed)
     else:
-        raise SystemExit('data sources: SyntheticWiderFace (ready batches) or SyntheticSourceImages '
-                         '(decoded sources + the reference train pipeline on the GPU); reading and '
-                         'decoding the WIDER files is outside the accelerated path')
+        raise SystemExit('data sources: RetinaFaceDataset (labelv2 + image files, augmented on the GPU), '
+                         'SyntheticWiderFace (ready batches) or SyntheticSourceImages (decoded synthetic '
+                         'sources + the reference train pipeline on the GPU)')
     meta = dict(config=args.config, seed=seed, CLASSES=('face',))
     R.train_detector(model, ds, cfg, distributed=distributed, validate=False, meta=meta,
                      max_iters=args.max_iters)
