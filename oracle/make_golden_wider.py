@@ -45,8 +45,36 @@ def run_reference(seed, **kw):
     return [float(a) for a in aps]
 
 
+def real_gt_preds(gt_dir, seed=0):
+    """Deterministic synthetic predictions over the REAL protocol ground truth
+    (data/widerface/labelv2/val/gt): 70 % of the faces, jittered, random scores."""
+    sys.path.insert(0, ROOT)
+    import yunet_amd.evaluation as E
+    ev = E.load_wider_gt(gt_dir)
+    rng = np.random.default_rng(seed)
+    pred = {}
+    for e in ev:
+        pred[e['name']] = {}
+        for im in e['images']:
+            b = im['boxes']
+            k = rng.uniform(size=len(b)) < 0.7
+            jit = b[k] + rng.normal(0, 0.05, (int(k.sum()), 4)) * b[k][:, [2, 3, 2, 3]]
+            sc = rng.uniform(0.2, 1, len(jit))
+            o = np.argsort(-sc, kind='stable')
+            pred[e['name']][im['name']] = np.concatenate([jit, sc[:, None]], 1)[o]
+    return ev, pred
+
+
 def main():
     out = {}
+    gt_dir = os.path.join(REF, 'data', 'widerface', 'labelv2', 'val', 'gt')
+    if '--real' in sys.argv and os.path.isdir(gt_dir):
+        _, pred = real_gt_preds(gt_dir)
+        with np.errstate(all='ignore'):
+            aps = reference_module().wider_evaluation(copy.deepcopy(pred), gt_dir, 0.5)
+        np.savez(os.path.join(ROOT, 'tests', 'golden', 'wider_eval_real.npz'), aps=np.array([float(a) for a in aps]))
+        print('real GT', aps)
+        return
     for seed, kw in ((0, dict()), (1, dict(n_events=4, imgs_per_event=7)), (2, dict(n_events=2, imgs_per_event=3))):
         out[f'aps_{seed}'] = np.array(run_reference(seed, **kw))
         out[f'cfg_{seed}'] = np.array([kw.get('n_events', 3), kw.get('imgs_per_event', 5)])

@@ -5,6 +5,8 @@ unmodified reference `simple_test` and against the CPU oracle.
 Scores / boxes go through expf on both sides, so values are compared to 1e-5 / 1e-3 px and the
 fixtures were selected with every decision (score threshold, IoU threshold, score order) at
 least 2e-5 / 2e-5 / 2e-7 away from its boundary; detections are matched in score order."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,3 +235,53 @@ def test_aug_test_single_view_twice_equals_simple_test():
     assert both.shape[1] == 5 and both.shape[0] >= 1
     assert np.all(np.diff(both[:, 4]) <= 0), 'descending score'
     assert np.isfinite(both).all() and (both[:, 2] > both[:, 0]).all() and (both[:, 3] > both[:, 1]).all()
+
+
+def test_widerface_tool_end_to_end(tmp_path):
+    """tools/test_widerface.py on a synthetic dataset in the protocol's own formats (labelv2 list, image
+    files, wider_*_val.mat): decode -> resize / pad -> eval forward -> get_bboxes(rescale) -> prediction
+    files -> APs; --eval-only over the saved files reproduces the same APs."""
+    import subprocess
+    import sys
+    from PIL import Image
+    import wider_fixture as WF
+    events, _ = WF.synth_events(7, n_events=2, imgs_per_event=3)
+    rng = np.random.default_rng(0)
+    lines = []
+    for ev in events:
+        os.makedirs(tmp_path / 'images' / ev['name'], exist_ok=True)
+        for im in ev['images']:
+            h, w = int(rng.integers(200, 420)), int(rng.integers(260, 520))
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(
+                tmp_path / 'images' / ev['name'] / (im['name'] + '.jpg'))
+            lines.append(f"# {ev['name']}/{im['name']}.jpg {w} {h}")
+            for b in im['boxes']:
+                lines.append('%d %d %d %d' % (b[0], b[1], b[0] + b[2], b[1] + b[3]))
+    os.makedirs(tmp_path / 'labelv2' / 'val', exist_ok=True)
+    (tmp_path / 'labelv2' / 'val' / 'labelv2.txt').write_text('\n'.join(lines) + '\n')
+    WF.write_mats(events, str(tmp_path / 'labelv2' / 'val' / 'gt'))
+    arch, sd = D.make_state('n', 5, size=160)
+    torch.save(dict(state_dict=sd, meta={}), tmp_path / 'ck.pth')
+    cfg = open('configs/yunet_n.py').read() + f"""
+data = dict(samples_per_gpu=1, test=dict(type='RetinaFaceDataset',
+            ann_file={str(tmp_path / 'labelv2' / 'val' / 'labelv2.txt')!r},
+            img_prefix={str(tmp_path / 'images')!r}, pipeline=[]))
+"""
+    (tmp_path / 'cfg.py').write_text(cfg)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    aps = {}
+    for mode in (2, 320):
+        out = tmp_path / f'out{mode}'
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'test_widerface.py'), str(tmp_path / 'cfg.py'),
+                            str(tmp_path / 'ck.pth'), '--out', str(out), '--save-preds', '--mode', str(mode), '--thr', '0.3'],
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-1500:]
+        aps[mode] = [float(v) for v in open(out / 'aps').read().strip().split(',')]
+        assert len(aps[mode]) == 3 and all(0.0 <= v <= 1.0 for v in aps[mode])
+        assert sum(len(os.listdir(out / e['name'])) for e in events) == 6
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'test_widerface.py'), str(tmp_path / 'cfg.py'),
+                        '--eval-only', str(tmp_path / 'out2'), '--out', str(tmp_path / 'again')],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    again = [float(v) for v in open(tmp_path / 'again' / 'aps').read().strip().split(',')]
+    assert again == pytest.approx(aps[2], abs=2e-4)          # text files keep 5 decimals

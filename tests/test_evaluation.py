@@ -95,3 +95,17 @@ def test_image_eval_matches_sequential_definition():
                     recall_list[m] = 1
             want_rec[h] = (recall_list == 1).sum()
         assert np.array_equal(rec, want_rec) and np.array_equal(prop, want_prop)
+
+
+REAL_GT = '/root/reference/data/widerface/labelv2/val/gt'
+
+
+@pytest.mark.skipif(not os.path.isdir(REAL_GT), reason='reference tree not present')
+def test_real_protocol_ground_truth_matches_reference_aps():
+    """The real wider_*_val.mat files (3226 images) + deterministic synthetic predictions: APs equal the
+    ones the unmodified reference function produced for the same inputs (oracle/make_golden_wider.py --real)."""
+    import make_golden_wider as MG
+    import yunet_amd.evaluation as E
+    ev, pred = MG.real_gt_preds(REAL_GT)
+    aps = E.wider_evaluation(pred, ev)
+    assert np.allclose(aps, Hh.load_golden('wider_eval_real.npz')['aps'], rtol=0, atol=1e-12)
