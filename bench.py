@@ -49,6 +49,9 @@ def parse():
     p.add_argument('--no-gpu-eager', action='store_true',
                    help='skip the un-accelerated-GPU row (the oracle\'s eager torch ops on cuda:0)')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                   help="f32: the headline line (BASELINE configs[1]); bf16: activation storage + forward matrix "
+                        "instruction in bf16, fp32 gradients / weights (configs[2]) -- a SECOND line, never the headline")
     return p.parse_args()
 
 
@@ -76,26 +79,32 @@ def self_launch(a):
 
 # ----------------------------------------------------------------- algorithmic byte model
 def op_bytes(op, L):
-    """Algorithmic HBM bytes of one launch (SURVEY.md 8d 'unit-boundary traffic', fp32):
-    forward unit = in + out, backward unit = 2*in + out; weights negligible."""
+    """Algorithmic HBM bytes of one launch (SURVEY.md 8d 'unit-boundary traffic'):
+    forward unit = in + out, backward unit = saved in + grad-out read + grad-in written
+    (2*in + out elements); weights negligible.  fp32: 4 B per element.  bf16 mode: ACTIVATIONS
+    (forward tensors, saved inputs) 2 B, gradients and the head output 4 B."""
     oc = op.opcode
     if oc in (L.OP_DP_FWD, L.OP_DP_BWD):
         d = op.dp
         px = d.N * d.H * d.W
-        i, o = px * d.cin * 4, px * d.cout * 4
-        return i + o if oc == L.OP_DP_FWD else 2 * i + o
+        xb = 2 if d.x_dtype == L.BF16 else 4
+        zb = 2 if d.z_dtype == L.BF16 else 4
+        if oc == L.OP_DP_FWD:
+            return px * (d.cin * xb + d.cout * zb)
+        return px * (d.cin * xb + d.cin * 4 + d.cout * 4)
+    ab = 2 if op.i[11] == L.BF16 else 4
     if oc in (L.OP_STEM_FWD, L.OP_STEM_BWD):
         n, h, w = op.i[0], op.i[1], op.i[2]
-        i, o = n * 3 * h * w * 4, n * (h // 2) * (w // 2) * 16 * 4
-        return i + o if oc == L.OP_STEM_FWD else 2 * i + o
+        i, o = n * 3 * h * w * 4, n * (h // 2) * (w // 2) * 16
+        return i + o * ab if oc == L.OP_STEM_FWD else 2 * i + o * 4
     if oc in (L.OP_POOL_FWD, L.OP_POOL_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
-        i, o = n * h * w * c * 4, n * h * w * c
-        return i + o if oc == L.OP_POOL_FWD else 2 * i + o
+        i, o = n * h * w * c, n * h * w * c // 4
+        return (i + o) * ab if oc == L.OP_POOL_FWD else i * ab + i * 4 + o * 4
     if oc in (L.OP_UPADD_FWD, L.OP_UPADD_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
-        a, b = n * h * w * c * 4, n * h * w * c
-        return (a + b + a) if oc == L.OP_UPADD_FWD else 2 * (a + b) + a
+        a, b = n * h * w * c, n * h * w * c // 4
+        return (a + b + a) * ab if oc == L.OP_UPADD_FWD else (a + b) * ab + (a + b) * 4 + a * 4
     if oc == L.OP_LOSS:
         return op.i[0] * op.i[1] * 16 * 4 * 2
     if oc == L.OP_ASSIGN:
@@ -150,8 +159,12 @@ def op_name(op, L):
         packed = (d.cin == 64 and d.cout in (64, 16) and d.H <= 20 and d.W <= 20 and d.N >= 4
                   and not os.environ.get('YUNET_NO_PACK'))
         kind = 'fwd' if op.opcode == L.OP_DP_FWD else 'bwd'
+        # backward: last template argument 1 = split-bf16 matrix path (64 -> 64 units), 0 = exact fp32
+        gemm = ''
+        if kind == 'bwd':
+            gemm = ',1' if (d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA')) else ',0'
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"
-                f"{'true' if packed and not big else 'false'}>")
+                f"{'true' if packed and not big else 'false'}{gemm}>")
     return names.get(op.opcode, f'op{op.opcode}')
 
 
@@ -335,6 +348,8 @@ def main():
     torch.manual_seed(0)
     model = yunet_amd.build_detector(cfg.model).to(dev)
     model.train()
+    if a.dtype == 'bf16':
+        model.set_precision('bf16')
     wrapped = YuNetDistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     opt = FusedSGD(model, lr=cfg.optimizer['lr'] * 0.001, momentum=cfg.optimizer['momentum'],
                    weight_decay=cfg.optimizer['weight_decay'])   # lr at warm-up iteration 0
@@ -377,15 +392,17 @@ def main():
     res = None
     if rank == 0:
         res = {
-            'metric': 'training images/sec, YuNet_n 320x320 bs=256/GPU' if (a.kind, a.size, a.batch) == (KIND, H, BATCH)
-            else f'training images/sec, YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU',
+            'metric': ('training images/sec, YuNet_n 320x320 bs=256/GPU' if (a.kind, a.size, a.batch) == (KIND, H, BATCH)
+                       else f'training images/sec, YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU') +
+            (', bf16 fwd / fp32 grads' if a.dtype == 'bf16' else ''),
             'value': round(world * a.batch * a.steps / dt, 1), 'unit': 'images/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU full training '
                                    'step (fwd + SimOTA + losses + bwd + grad all-reduce + SGD), '
-                                   'synthetic WIDER-Face-shaped batches, fp32',
+                                   'synthetic WIDER-Face-shaped batches, ' +
+                                   ('fp32' if a.dtype == 'f32' else 'bf16 activations + bf16 forward matrix instruction, fp32 gradients / weights'),
                        'parallelism': f'dp{world}', 'global_batch': world * a.batch},
             'final_loss': round(last_loss, 4),
             'per_rank_images_per_sec': [round(a.batch * a.steps / t, 1) for t in per_rank],

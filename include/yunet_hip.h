@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 1
+#define YUNET_ABI_VERSION 2
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -46,6 +46,13 @@ typedef struct YunetBN {
 
 /* Input transform of a fused unit (how it reads its input tensor). */
 enum { YUNET_T_IDENTITY = 0, YUNET_T_BNRELU = 1 };
+
+/* Storage type of ACTIVATION tensors (raw conv outputs, pool / upsample-add outputs).  YUNET_BF16 is
+ * BASELINE.json configs[2] "bf16 fwd / fp32 grads": activations are kept as bf16 in HBM and the
+ * forward pointwise GEMM runs on the bf16 matrix instruction; gradients, the head output
+ * [N,P,16], BatchNorm sums, parameters and the optimizer stay fp32.  (The reference's analogue is
+ * its fp16 path: mmdet/apis/train.py:181-185, detectors/base.py:168, yunet_head.py:418 force_fp32.) */
+enum { YUNET_F32 = 0, YUNET_BF16 = 1 };
 
 /* One ConvDPUnit: 1x1 pointwise (bias) -> 3x3 depthwise (bias, zero-pads the pointwise
  * output) [-> BN -> ReLU applied by the consumer].
@@ -73,6 +80,8 @@ typedef struct YunetDP {
     float* wgrad_partials;     /* [nblocks, cout*cin + cout + cout*9 + cout] fp32     */
     int32_t wgrad_blocks;      /* number of partial rows (= launch grid)              */
     unsigned long long* prof;  /* optional [grid,8] per-workgroup phase cycle counters (or NULL) */
+    int32_t x_dtype;           /* YUNET_F32 | YUNET_BF16: storage of x (and of z unless z_dtype says otherwise) */
+    int32_t z_dtype;           /* storage of z: equals x_dtype, except the fused heads, whose z is the fp32 [N,P,16] */
 } YunetDP;
 
 /* ---- conv stack (mmdet/models/utils/yunet_layer.py, backbones/yunet_backbone.py:33-41,
@@ -236,6 +245,28 @@ typedef struct YunetOp {
     YunetLossCfg loss;
 } YunetOp;
 int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
+
+/* ---- the conv stack with bf16 activation storage (YUNET_BF16, see the enum above) ----------------
+ * Same arguments as the entry points without the suffix; pointers to ACTIVATION tensors (z, x, pool /
+ * upsample-add inputs and outputs) then address bf16 elements, everything else (image, dy, dx, the
+ * heads' [N,P,16] output, weights, partials, BN sums) is fp32 / fp64 as before.  yunet_exec selects
+ * them per op (YunetDP.x_dtype, YunetOp.i[11]). */
+int yunet_stem_fwd_bf16(const float* img, const float* w, const float* b, float* z, double* stats,
+                        int N, int H, int W, int cmid, void* stream);
+int yunet_stem_bwd_bf16(const float* img, const float* z, const float* dy, const YunetBN* bn,
+                        float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
+                        void* stream);
+int yunet_dp_fwd_bf16(const YunetDP* d, void* stream);
+int yunet_dp_bwd_bf16(const YunetDP* d, void* stream);
+int yunet_pool_fwd_bf16(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
+                        void* stream);
+int yunet_pool_bwd_bf16(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
+                        int accumulate, int N, int H, int W, int C, void* stream);
+int yunet_upadd_fwd_bf16(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
+                         float* out, int N, int H, int W, int C, void* stream);
+int yunet_upadd_bwd_bf16(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
+                         const float* dout, float* dxa, int accumulate_a, float* dxb,
+                         int accumulate_b, int N, int H, int W, int C, void* stream);
 
 /* ---- detection post-processing -------------------------------------
  * YuNet_Head.get_bboxes (mmdet/models/dense_heads/yunet_head.py:290-416): priors, sigmoid scores

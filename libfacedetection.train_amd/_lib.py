@@ -14,6 +14,7 @@ c_f32p = C.c_void_p
 MAX_LEVELS = 5
 
 T_IDENTITY, T_BNRELU = 0, 1
+F32, BF16 = 0, 1
 BOX_EIOU, BOX_DIOU = 0, 1
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
@@ -34,7 +35,7 @@ class YunetDP(C.Structure):
                 ('b_dw', C.c_void_p), ('z', C.c_void_p), ('out_bn', YunetBN),
                 ('dy', C.c_void_p), ('dy_scale', C.c_void_p), ('dx', C.c_void_p),
                 ('wgrad_partials', C.c_void_p), ('wgrad_blocks', C.c_int32),
-                ('prof', C.c_void_p)]
+                ('prof', C.c_void_p), ('x_dtype', C.c_int32), ('z_dtype', C.c_int32)]
 
 
 class YunetLevels(C.Structure):
@@ -108,6 +109,10 @@ _SIGNATURES = {
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
 }
+for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
+           'yunet_upadd_fwd', 'yunet_upadd_bwd'):
+    _SIGNATURES[_n + '_bf16'] = _SIGNATURES[_n]      # same arguments, bf16 activation storage
+
 EXPORTED = sorted(_SIGNATURES)
 
 _lib = None
@@ -132,7 +137,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 1:
+    if lib.yunet_abi_version() != 2:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -76,41 +76,56 @@ extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum
     return hip_status();
 }
 
+// the same conv entry points compiled with bf16 activation storage (conv_fwd.hip / conv_bwd.hip -DYUNET_ACT_BF16)
+extern "C" {
+int yunet_stem_fwd_bf16(const float*, const float*, const float*, float*, double*, int, int, int, int, void*);
+int yunet_stem_bwd_bf16(const float*, const float*, const float*, const YunetBN*, float*, int, int, int, int, int, void*);
+int yunet_dp_fwd_bf16(const YunetDP*, void*);
+int yunet_dp_bwd_bf16(const YunetDP*, void*);
+int yunet_pool_fwd_bf16(const float*, const YunetBN*, float*, int, int, int, int, void*);
+int yunet_pool_bwd_bf16(const float*, const YunetBN*, const float*, float*, int, int, int, int, int, void*);
+int yunet_upadd_fwd_bf16(const float*, const YunetBN*, const float*, const YunetBN*, float*, int, int, int, int, void*);
+int yunet_upadd_bwd_bf16(const float*, const YunetBN*, const float*, const YunetBN*, const float*, float*, int, float*,
+                         int, int, int, int, int, void*);
+}
+
+// Op lists select the activation storage type per op: YunetDP.x_dtype for the ConvDPUnits, i[11] for
+// the stem / pool / upsample-add ops (0 = fp32, 1 = bf16).
 extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
     for (int k = 0; k < n_ops; ++k) {
         const YunetOp& o = ops[k];
         int rc = 0;
         switch (o.opcode) {
             case YUNET_OP_STEM_FWD:
-                rc = yunet_stem_fwd((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_stem_fwd_bf16 : yunet_stem_fwd)((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                     (float*)o.p[3], (double*)o.p[4], o.i[0], o.i[1], o.i[2], o.i[3],
                                     stream);
                 break;
             case YUNET_OP_STEM_BWD:
-                rc = yunet_stem_bwd((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_stem_bwd_bf16 : yunet_stem_bwd)((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                     &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3],
                                     stream);
                 break;
             case YUNET_OP_DP_FWD:
-                rc = yunet_dp_fwd(&o.dp, stream);
+                rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_fwd_bf16(&o.dp, stream) : yunet_dp_fwd(&o.dp, stream);
                 break;
             case YUNET_OP_DP_BWD:
-                rc = yunet_dp_bwd(&o.dp, stream);
+                rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_bwd_bf16(&o.dp, stream) : yunet_dp_bwd(&o.dp, stream);
                 break;
             case YUNET_OP_POOL_FWD:
-                rc = yunet_pool_fwd((const float*)o.p[0], &o.bn[0], (float*)o.p[1], o.i[0], o.i[1],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_fwd_bf16 : yunet_pool_fwd)((const float*)o.p[0], &o.bn[0], (float*)o.p[1], o.i[0], o.i[1],
                                     o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_POOL_BWD:
-                rc = yunet_pool_bwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_bwd_bf16 : yunet_pool_bwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1],
                                     (float*)o.p[2], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_UPADD_FWD:
-                rc = yunet_upadd_fwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_upadd_fwd_bf16 : yunet_upadd_fwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
                                      (float*)o.p[2], o.i[0], o.i[1], o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_UPADD_BWD:
-                rc = yunet_upadd_bwd((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
+                rc = (o.i[11] == YUNET_BF16 ? yunet_upadd_bwd_bf16 : yunet_upadd_bwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],
                                      (const float*)o.p[2], (float*)o.p[3], o.i[4], (float*)o.p[4],
                                      o.i[5], o.i[0], o.i[1], o.i[2], o.i[3], stream);
                 break;

@@ -13,6 +13,73 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- activation storage type of this translation unit ------------------------------------------
+// conv_fwd.hip / conv_bwd.hip are compiled twice: as is (fp32 activations, the headline path) and with
+// -DYUNET_ACT_BF16 (BASELINE.json configs[2]: "bf16 fwd / fp32 grads").  In the second build every
+// ACTIVATION tensor a forward kernel writes (raw conv outputs z, pool / upsample-add outputs) is stored
+// as bf16 (round to nearest even) and every kernel that reads one widens it on load; gradients (dy, dx),
+// the head output `flat`, BatchNorm sums (taken from the fp32 values before rounding), weights and the
+// optimizer stay fp32.  The exported entry points of that build carry the suffix _bf16.
+#ifdef YUNET_ACT_BF16
+typedef unsigned short act_t;
+typedef u32x2 act_raw4;                     // raw bits of 4 consecutive channels
+#define ACT_SUFFIX(name) name##_bf16
+#define YUNET_ACT_DTYPE YUNET_BF16
+#else
+typedef float act_t;
+typedef u32x4 act_raw4;
+#define ACT_SUFFIX(name) name
+#define YUNET_ACT_DTYPE YUNET_F32
+#endif
+#define ACT_B ((unsigned)sizeof(act_t))
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {      // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float4 act_unpack(const act_raw4 r) {
+#ifdef YUNET_ACT_BF16
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+#else
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+#endif
+}
+__device__ __forceinline__ act_raw4 act_pack(const float4 v) {
+#ifdef YUNET_ACT_BF16
+    return act_raw4{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+#else
+    return act_raw4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#endif
+}
+// 4 consecutive channels through a buffer descriptor (byte offset; out-of-range offsets read 0 / drop)
+template <typename R>
+__device__ __forceinline__ act_raw4 act_bufld4(R rsrc, unsigned byte_off) {
+#ifdef YUNET_ACT_BF16
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0);
+#else
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+#endif
+}
+template <typename R>
+__device__ __forceinline__ void act_bufst4(R rsrc, unsigned byte_off, const float4 v) {
+#ifdef YUNET_ACT_BF16
+    __builtin_amdgcn_raw_buffer_store_b64(act_pack(v), rsrc, byte_off, 0, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(act_pack(v), rsrc, byte_off, 0, 0);
+#endif
+}
+// the same through plain pointers (element-wise kernels)
+__device__ __forceinline__ float4 act_ld4(const act_t* p) {
+    return act_unpack(*reinterpret_cast<const act_raw4*>(p));
+}
+__device__ __forceinline__ void act_st4(act_t* p, const float4 v) {
+    *reinterpret_cast<act_raw4*>(p) = act_pack(v);
+}
 
 // D = A(16x4) * B(4x16) + C, exact fp32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];

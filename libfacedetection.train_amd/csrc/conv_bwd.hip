@@ -200,9 +200,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     // outside the image (zero padding of the halo, ragged last tiles) simply gets an offset past
     // the end -- the hardware range check returns 0, so there are no branches and no 64-bit
     // address arithmetic.  okmask keeps one validity bit per halo slot for the stage.
-    float4 pdy[G::NDZ], pz[G::NDZ], px[G::NX];
+    float4 pdy[G::NDZ];
+    act_raw4 pz[G::NDZ], px[G::NX];          // saved activations: storage type of this build (fp32 | bf16)
     unsigned okmask = 0;
-    const unsigned zbytes = (unsigned)(H * W * COUT) * 4u, xbytes = (unsigned)(H * W * CIN) * 4u;
+    // dy / dx are fp32 in every build; z and x are activations
+    const unsigned dybytes = (unsigned)(H * W * COUT) * 4u, zbytes = (unsigned)(H * W * COUT) * ACT_B;
+    const unsigned xbytes = (unsigned)(H * W * CIN) * ACT_B, dxbytes = (unsigned)(H * W * CIN) * 4u;
     constexpr int PSTEP = BWD_THREADS / G::C4O;            // halo pixels between a thread's slots
     // issue(t, part): part -1 = everything at once; parts 0..3 = x | first | second | last third of the
     // (dy, z) slots.  A CU keeps far fewer bytes in flight than the 124 KB of a tile: issued in one go
@@ -215,13 +218,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
         // packed: descriptors over the whole tensors, the image index is part of the offset
-        const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : zbytes;
-        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
+        const unsigned dyrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : dybytes;
+        const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * ACT_B : zbytes;
+        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * ACT_B : xbytes;
         const size_t zbase = PACKED ? (size_t)0 : (size_t)n * d.z_img_stride;
         const size_t xbase = PACKED ? (size_t)0 : (size_t)n * d.x_img_stride;
-        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy) + zbase, 0, zrange, 0x00020000);
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z) + zbase, 0, zrange, 0x00020000);
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + xbase, 0, xrange, 0x00020000);
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy) + zbase, 0, dyrange, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xrange, 0x00020000);
         if (PART <= 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < G::NDZ; ++i) {
@@ -230,23 +236,20 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             bool ok;
-            unsigned off;
+            unsigned eo;                              // element offset of the slot
             if constexpr (PACKED) {
                 int pn, py, px;
                 ok = hp < G::HP && pk_locate(pk, y, x, pn, py, px);
-                off = ok ? (unsigned)(pn * d.z_img_stride + (py * W + px) * COUT + och4 * 4) * 4u : zrange;
+                eo = (unsigned)(pn * d.z_img_stride + (py * W + px) * COUT + och4 * 4);
             } else {
                 ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                off = ok ? (unsigned)((y * W + x) * COUT + och4 * 4) * 4u : zbytes;
+                eo = (unsigned)((y * W + x) * COUT + och4 * 4);
             }
             okmask |= ok ? (1u << i) : 0u;
-            const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, off, 0, 0);
+            const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dyrange, 0, 0);
             pdy[i] = *reinterpret_cast<const float4*>(&vdy);
-            pz[i] = make_float4(0, 0, 0, 0);
-            if (bn_out) {
-                const u32x4 vz = __builtin_amdgcn_raw_buffer_load_b128(r_z, off, 0, 0);
-                pz[i] = *reinterpret_cast<const float4*>(&vz);
-            }
+            pz[i] = act_raw4{};
+            if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zrange);
             // packed: finish one slot's address arithmetic before the next one starts (otherwise
             // all 16 canvas -> image mappings are computed up front and spill)
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
@@ -260,12 +263,11 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             if constexpr (PACKED) {
                 int pn, py, px;
                 off = pk_locate(pk, y, x, pn, py, px)
-                          ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * 4u : xrange;
+                          ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * ACT_B : xrange;
             } else {
-                off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+                off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * ACT_B : xbytes;
             }
-            const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
-            px[i] = *reinterpret_cast<const float4*>(&vx);
+            px[i] = act_bufld4(r_x, off);
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             for (int i = 0; i < G::NDZ; ++i) {
                 const int hp = hp0 + PSTEP * i;
                 if ((i + 1) * PSTEP <= G::HP || hp < G::HP) {
-                    const float4 dy = pdy[i], z = pz[i];
+                    const float4 dy = pdy[i], z = act_unpack(pz[i]);
                     float4 v;
                     if (bn_out) {
                         // zero padding of dz: a slot outside the image loaded dy = z = 0, which the
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #pragma unroll
             for (int i = 0; i < G::NX; ++i) {
                 const int ip = (tid + BWD_THREADS * i) / G::C4I;
-                *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = px[i];
+                *reinterpret_cast<float4*>(s_a + ip * G::LSI + ich4 * 4) = act_unpack(px[i]);
             }
         }
         __syncthreads();
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         if (d.dx && !(abl & 16)) {
             const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
             const int ich4 = tid % G::C4I;
-            const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
+            const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : dxbytes;
             const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(
                 d.dx + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
             unsigned off[G::NX];
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                     off[i] = pk_locate(pk, y, x, pn, py, px)
                                  ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * 4u : xrange;
                 } else {
-                    off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : xbytes;
+                    off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : dxbytes;
                 }
             }
             // two separate paths: the plain store must not wait on the vector-memory counter (the next
@@ -934,7 +936,7 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
 #define SB_TW 32
 #define SB_TH 8
 __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ img,
-                                                       const float* __restrict__ z,
+                                                       const act_t* __restrict__ z,
                                                        const float* __restrict__ dy, YunetBN bn,
                                                        float* __restrict__ partials, int N, int H,
                                                        int W) {
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
             if (oy < Ho && ox < Wo) {
                 const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * 16 + lc4 * 4;
                 const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
-                const float4 z4 = *reinterpret_cast<const float4*>(z + off);
+                const float4 z4 = act_ld4(z + off);
                 v.x = bn_dz(g4.x, z4.x, km[0], kml[0], ki[0], k1[0], c1[0], c1l[0], c2[0]);
                 v.y = bn_dz(g4.y, z4.y, km[1], kml[1], ki[1], k1[1], c1[1], c1l[1], c2[1]);
                 v.z = bn_dz(g4.z, z4.z, km[2], kml[2], ki[2], k1[2], c1[2], c1l[2], c2[2]);
@@ -1080,7 +1082,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------- pool / upsample-add
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ z, YunetBN bn,
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const act_t* __restrict__ z, YunetBN bn,
                                                        const float* __restrict__ dyo,
                                                        float* __restrict__ dx, int accumulate, int N,
                                                        int H, int W, int C) {
@@ -1104,8 +1106,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         float zv[4][4], yv[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(
-                z + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
+            const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
             zv[j][0] = v.x; zv[j][1] = v.y; zv[j][2] = v.z; zv[j][3] = v.w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) yv[j][i] = bnrelu(zv[j][i], k[i].mean, k[i].scale, k[i].beta);
@@ -1150,8 +1151,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict__ za, YunetBN bna,
-                                                        const float* __restrict__ zb, YunetBN bnb,
+__global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict__ za, YunetBN bna,
+                                                        const act_t* __restrict__ zb, YunetBN bnb,
                                                         const float* __restrict__ dout,
                                                         float* __restrict__ dxa, int acc_a,
                                                         float* __restrict__ dxb, int acc_b, int N,
@@ -1180,7 +1181,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j) {
             const size_t off = (((size_t)n * H + 2 * by + (j >> 1)) * W + 2 * bx + (j & 1)) * C + c4 * 4;
             const float4 g4 = *reinterpret_cast<const float4*>(dout + off);
-            const float4 z4 = *reinterpret_cast<const float4*>(za + off);
+            const float4 z4 = act_ld4(za + off);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
             float o[4];
 #pragma unroll
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict_
             *dst = v;
         }
         const size_t offb = (((size_t)n * Hb + by) * Wb + bx) * C + c4 * 4;
-        const float4 zb4 = *reinterpret_cast<const float4*>(zb + offb);
+        const float4 zb4 = act_ld4(zb + offb);
         const float zbv[4] = {zb4.x, zb4.y, zb4.z, zb4.w};
         float ob[4];
 #pragma unroll
@@ -1239,6 +1240,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const float* __restrict_
 #undef UPADD_FLUSH
 }
 
+#ifndef YUNET_ACT_BF16
 __global__ void bn_param_grad_kernel(const double* __restrict__ bstats, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1292,6 +1294,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const Yunet
     }
 }
 
+#endif
+
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -1304,6 +1308,10 @@ inline int ew_grid(long long total) {
 static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
     return cin == 16 && cout == 16 && W >= 64 && H >= 32;
 }
+#ifdef YUNET_ACT_BF16
+extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
+extern "C" int yunet_stem_bwd_blocks(int N, int H, int W);
+#else
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
     const int th = dp_bwd_big_tile(H, W, cin, cout) ? 16 : 8, tw = th * 2;
     const PackGeom pk = dp_pack_geom(N, H, W);       // small maps: one tile grid over the packed canvas
@@ -1316,9 +1324,11 @@ extern "C" int yunet_stem_bwd_blocks(int N, int H, int W) {
     const long long tiles = (long long)N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
     return (int)(tiles < STEM_BWD_MAX_BLOCKS ? tiles : STEM_BWD_MAX_BLOCKS);
 }
+#endif
 
-extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     if (!d->wgrad_partials ||
         d->wgrad_blocks != yunet_dp_bwd_blocks(d->N, d->H, d->W, d->cin, d->cout))
         return YUNET_EINVAL;   // the partial buffer must have exactly the rows the grid writes
@@ -1346,39 +1356,41 @@ extern "C" int yunet_dp_bwd(const YunetDP* d, void* stream) {
     return YUNET_EINVAL;
 }
 
-extern "C" int yunet_stem_bwd(const float* img, const float* z, const float* dy, const YunetBN* bn,
-                              float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
-                              void* stream) {
+extern "C" int ACT_SUFFIX(yunet_stem_bwd)(const float* img, const float* z, const float* dy, const YunetBN* bn,
+                                          float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
+                                          void* stream) {
     if (cmid != 16 || (H & 1) || (W & 1) || wgrad_blocks != yunet_stem_bwd_blocks(N, H, W))
         return YUNET_EINVAL;
     const int tiles = N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > wgrad_blocks) grid = wgrad_blocks;
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, z, dy, *bn,
-                       wgrad_partials, N, H, W);
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img,
+                       reinterpret_cast<const act_t*>(z), dy, *bn, wgrad_partials, N, H, W);
     return hip_status();
 }
 
-extern "C" int yunet_pool_bwd(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
-                              int accumulate, int N, int H, int W, int C, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_pool_bwd)(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
+                                          int accumulate, int N, int H, int W, int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z, *bn,
-                       dy_out, dx, accumulate, N, H, W, C);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const act_t*>(z), *bn, dy_out, dx, accumulate, N, H, W, C);
     return hip_status();
 }
 
-extern "C" int yunet_upadd_bwd(const float* za, const YunetBN* bna, const float* zb,
-                               const YunetBN* bnb, const float* dout, float* dxa, int accumulate_a,
-                               float* dxb, int accumulate_b, int N, int H, int W, int C,
-                               void* stream) {
+extern "C" int ACT_SUFFIX(yunet_upadd_bwd)(const float* za, const YunetBN* bna, const float* zb,
+                                           const YunetBN* bnb, const float* dout, float* dxa, int accumulate_a,
+                                           float* dxb, int accumulate_b, int N, int H, int W, int C,
+                                           void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, za,
-                       *bna, zb, *bnb, dout, dxa, accumulate_a, dxb, accumulate_b, N, H, W, C);
+    hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const act_t*>(za), *bna, reinterpret_cast<const act_t*>(zb), *bnb, dout, dxa,
+                       accumulate_a, dxb, accumulate_b, N, H, W, C);
     return hip_status();
 }
 
+#ifndef YUNET_ACT_BF16
 extern "C" int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C,
                                    int accumulate, void* stream) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
@@ -1401,3 +1413,4 @@ extern "C" int yunet_reduce_partials_batch(const YunetReduceJob* jobs, int njobs
                        (hipStream_t)stream, jobs, njobs);
     return hip_status();
 }
+#endif

@@ -28,7 +28,7 @@ namespace {
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ img,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ b,
-                                                       float* __restrict__ z,
+                                                       act_t* __restrict__ z,
                                                        double* __restrict__ stats, int N, int H,
                                                        int W) {
     constexpr int PH = 2 * STEM_TH + 1;                 // patch rows per channel
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         for (int p = 0; p < STEM_PX; ++p) {
             const int ox = x0 + STEM_PX * cg + p;
             if (oy < Ho && ox < Wo) {
-                float4* dst = reinterpret_cast<float4*>(z + (((size_t)n * Ho + oy) * Wo + ox) * 16);
+                act_t* dst = z + (((size_t)n * Ho + oy) * Wo + ox) * 16;
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4)
-                    dst[c4] = make_float4(acc[p][c4 * 4], acc[p][c4 * 4 + 1], acc[p][c4 * 4 + 2],
-                                          acc[p][c4 * 4 + 3]);
+                    act_st4(dst + 4 * c4, make_float4(acc[p][c4 * 4], acc[p][c4 * 4 + 1], acc[p][c4 * 4 + 2],
+                                                      acc[p][c4 * 4 + 3]));
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     ts[c] += acc[p][c];
@@ -223,17 +223,21 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     // a per-image buffer descriptor: one 32-bit byte offset per slot, and a slot outside the
     // image gets an offset past the end (the hardware range check returns 0) -- no branches, no
     // 64-bit address arithmetic
-    float4 pre[G::NLD];
-    const unsigned xbytes = (unsigned)(H * W * CIN) * 4u, zbytes = (unsigned)(H * W * COUT) * 4u;
+    act_raw4 pre[G::NLD];
+    // the fused heads write the fp32 [N,P,16] prediction tensor whatever the activation type is
+    const bool z_f32 = YUNET_ACT_DTYPE == YUNET_F32 || (COUT == 16 && d.z_dtype == YUNET_F32);
+    const unsigned ZB = z_f32 ? 4u : ACT_B;
+    const unsigned xbytes = (unsigned)(H * W * CIN) * ACT_B, zbytes = (unsigned)(H * W * COUT) * ZB;
     constexpr int PSTEP = 256 / G::C4I;                   // halo pixels between a thread's slots
     constexpr int HSTEP_Y = PSTEP / G::HW_, HSTEP_X = PSTEP % G::HW_;
     auto issue = [&](int t) {
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;      // canvas coordinates if PACKED
         // packed: one descriptor over the whole tensor, the image index is part of the offset
-        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : xbytes;
+        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * ACT_B : xbytes;
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(d.x) + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
+            reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0,
+            xrange, 0x00020000);
         int hp = tid / G::C4I;
         int hy = hp / G::HW_, hx = hp - hy * G::HW_;
 #pragma unroll
@@ -244,13 +248,12 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
             if constexpr (PACKED) {
                 int pn, py, px;
                 ok = hp < G::HP && pk_locate(pk, y, x, pn, py, px);
-                off = ok ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + lch4 * 4) * 4u : xrange;
+                off = ok ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + lch4 * 4) * ACT_B : xrange;
             } else {
                 ok = hp < G::HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                off = ok ? (unsigned)((y * W + x) * CIN + lch4 * 4) * 4u : xbytes;
+                off = ok ? (unsigned)((y * W + x) * CIN + lch4 * 4) * ACT_B : xbytes;
             }
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0);
-            pre[i] = *reinterpret_cast<const float4*>(&v);
+            pre[i] = act_bufld4(r_x, off);
             hp += PSTEP; hy += HSTEP_Y; hx += HSTEP_X;
             if (hx >= G::HW_) { hx -= G::HW_; ++hy; }
         }
@@ -259,7 +262,17 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     int t = blockIdx.x;
     if (t < ntiles) issue(t);
 
-    for (int i = tid; i < COUT * CIN; i += 256) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+    // bf16 build, 32 / 64 input channels: the pointwise GEMM runs on v_mfma_f32_16x16x32_bf16 (16x the
+    // fp32 matrix rate) with a = bf16(relu(bn(x))) and W1 rounded to bf16 ("bf16 forward"); the 16-channel
+    // units (K = 16, HBM-bound) keep the fp32 instruction
+    constexpr bool BF16_MMA = YUNET_ACT_DTYPE == YUNET_BF16 && CIN % 32 == 0;
+    constexpr int WSB = CIN + 8;                                      // bf16 weight row stride (elements)
+    __bf16* s_w1b = reinterpret_cast<__bf16*>(s_w1);                  // [COUT][WSB], inside the fp32-sized block
+    if constexpr (BF16_MMA) {
+        for (int i = tid; i < COUT * CIN; i += 256) s_w1b[(i / CIN) * WSB + (i % CIN)] = (__bf16)d.w_pw[i];
+    } else {
+        for (int i = tid; i < COUT * CIN; i += 256) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+    }
     for (int i = tid; i < COUT * 9; i += 256) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
     for (int i = tid; i < COUT; i += 256) s_b2[i] = d.b_dw[i];
     for (int c = tid; c < CIN; c += 256) {
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                 if ((i + 1) * PSTEP <= G::MP || hp < G::MP) {
                     // (halo pixels outside the image hold T(0) here; their pointwise output is
                     // forced to zero in the pw epilogue, which is what the depthwise pads with)
-                    float4 v = pre[i];
+                    float4 v = act_unpack(pre[i]);
                     v.x = fmaxf(fmaf(v.x - cm.x, cs.x, cb.x), relu_floor);
                     v.y = fmaxf(fmaf(v.y - cm.y, cs.y, cb.y), relu_floor);
                     v.z = fmaxf(fmaf(v.z - cm.z, cs.z, cb.z), relu_floor);
@@ -322,6 +335,25 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
             f32x4 acc[G::NT];
 #pragma unroll
             for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF16_MMA) {
+                // lane group g supplies input channels 32*kb + 8g .. +7 on both sides
+                typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+                const float* arow = buf + (mt * 16 + l15) * G::LS + 8 * g;
+                const __bf16* brow = s_w1b + l15 * WSB + 8 * g;
+#pragma unroll
+                for (int kb = 0; kb < CIN / 32; ++kb) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(arow + 32 * kb);
+                    const float4 x1 = *reinterpret_cast<const float4*>(arow + 32 * kb + 4);
+                    const u32x4 ap = {pack_bf16x2(x0.x, x0.y), pack_bf16x2(x0.z, x0.w), pack_bf16x2(x1.x, x1.y),
+                                      pack_bf16x2(x1.z, x1.w)};
+                    const bf16x8_t av = __builtin_bit_cast(bf16x8_t, ap);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) {
+                        const u32x4 bp = *reinterpret_cast<const u32x4*>(brow + nt * 16 * WSB + 32 * kb);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bp), acc[nt], 0, 0, 0);
+                    }
+                }
+            } else {
             // MFMA operands are fetched four k-steps at a time with 16-byte LDS reads: k-step
             // (j, i) of lane group g multiplies input channel 16*j + 4*g + i (any permutation of
             // the reduction index is valid as long as A and B agree).
@@ -359,6 +391,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                 for (int nt = 0; nt < G::NT; ++nt) acc[nt] = mfma16(a4[j].w, bq[j & 1][nt].w, acc[nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int hp = mt * 16 + 4 * g + r;
@@ -378,9 +411,11 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
         if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }
         // ---- dw: depthwise 3x3 from LDS, bias, store raw z, BN statistics ------------------------
         if (!(abl & 2)) {
-            const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : zbytes;
+            const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * ZB : zbytes;
+            const size_t zimg = PACKED ? (size_t)0 : (size_t)n * d.z_img_stride;
             const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
-                d.z + (PACKED ? (size_t)0 : (size_t)n * d.z_img_stride), 0, zrange, 0x00020000);
+                z_f32 ? reinterpret_cast<void*>(d.z + zimg)
+                      : reinterpret_cast<void*>(reinterpret_cast<act_t*>(d.z) + zimg), 0, zrange, 0x00020000);
             const float* pbase = buf + dtx * G::LS + cq * 4;
             float4 w2[9];
 #pragma unroll
@@ -414,10 +449,13 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                 int pn = 0, py = y, px = x;
                 const bool inside = PACKED ? pk_locate(pk, y, x, pn, py, px) : (y < H && x < W);
                 if (inside) {
-                    if (!(abl & 4))
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            *reinterpret_cast<const u32x4*>(&o), r_z,
-                            (unsigned)(pn * (PACKED ? d.z_img_stride : 0) + (py * W + px) * COUT + cq * 4) * 4u, 0, 0);
+                    if (!(abl & 4)) {
+                        const unsigned zoff = (unsigned)(pn * (PACKED ? d.z_img_stride : 0) + (py * W + px) * COUT + cq * 4);
+                        if (z_f32)
+                            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z, zoff * 4u, 0, 0);
+                        else
+                            act_bufst4(r_z, zoff * ACT_B, o);
+                    }
                     ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
                     ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
                     ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
@@ -482,8 +520,8 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
 
 // ------------------------------------------------------------------- pool / upsample-add
 // one thread = one float4 of channels of one OUTPUT pixel
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ z, YunetBN bn,
-                                                       float* __restrict__ out, int N, int H, int W,
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__ z, YunetBN bn,
+                                                       act_t* __restrict__ out, int N, int H, int W,
                                                        int C) {
     const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
     const long long total = (long long)N * Ho * Wo * C4;
@@ -503,20 +541,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const float4 v = *reinterpret_cast<const float4*>(
-                    z + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
+                const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
                 m.x = fmaxf(m.x, bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta));
                 m.y = fmaxf(m.y, bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta));
                 m.z = fmaxf(m.z, bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta));
                 m.w = fmaxf(m.w, bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta));
             }
-        *reinterpret_cast<float4*>(out + e * 4) = m;
+        act_st4(out + e * 4, m);
     }
 }
 
-__global__ __launch_bounds__(256) void upadd_fwd_kernel(const float* __restrict__ za, YunetBN bna,
-                                                        const float* __restrict__ zb, YunetBN bnb,
-                                                        float* __restrict__ out, int N, int H, int W,
+__global__ __launch_bounds__(256) void upadd_fwd_kernel(const act_t* __restrict__ za, YunetBN bna,
+                                                        const act_t* __restrict__ zb, YunetBN bnb,
+                                                        act_t* __restrict__ out, int N, int H, int W,
                                                         int C) {
     const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
     const long long total = (long long)N * H * W * C4;
@@ -533,18 +570,18 @@ __global__ __launch_bounds__(256) void upadd_fwd_kernel(const float* __restrict_
         const int x = (int)(pix % W);
         pix /= W;
         const int y = (int)(pix % H), n = (int)(pix / H);
-        const float4 a = *reinterpret_cast<const float4*>(za + e * 4);
-        const float4 b = *reinterpret_cast<const float4*>(
-            zb + (((size_t)n * Hb + y / 2) * Wb + x / 2) * C + c4 * 4);
+        const float4 a = act_ld4(za + e * 4);
+        const float4 b = act_ld4(zb + (((size_t)n * Hb + y / 2) * Wb + x / 2) * C + c4 * 4);
         float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             o[i] = bnrelu(av[i], ka[i].mean, ka[i].scale, ka[i].beta) +
                    bnrelu(bv[i], kb[i].mean, kb[i].scale, kb[i].beta);
-        *reinterpret_cast<float4*>(out + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        act_st4(out + e * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
+#ifndef YUNET_ACT_BF16
 // running_mean/var update of one BN layer (nn.BatchNorm2d momentum 0.1, unbiased var)
 __global__ void bn_running_kernel(const double* __restrict__ stats, float* __restrict__ rm,
                                   float* __restrict__ rv, int C, int count, float momentum) {
@@ -558,6 +595,7 @@ __global__ void bn_running_kernel(const double* __restrict__ stats, float* __res
     rm[c] = (1.0f - momentum) * rm[c] + momentum * (float)mean;
     rv[c] = (1.0f - momentum) * rv[c] + momentum * (float)unb;
 }
+#endif
 
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
@@ -566,19 +604,21 @@ inline int ew_grid(long long total) {
 
 }  // namespace
 
-extern "C" int yunet_stem_fwd(const float* img, const float* w, const float* b, float* z,
-                              double* stats, int N, int H, int W, int cmid, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_stem_fwd)(const float* img, const float* w, const float* b, float* z,
+                                          double* stats, int N, int H, int W, int cmid, void* stream) {
     if (cmid != 16 || (H & 1) || (W & 1)) return YUNET_EINVAL;
     const int tiles = N * ((W / 2 + STEM_TW - 1) / STEM_TW) * ((H / 2 + STEM_TH - 1) / STEM_TH);
     // persistent grid = resident workgroups (158 VGPRs -> 3 waves/SIMD -> 3 per CU on 256 CUs)
     const int grid = tiles < 768 ? tiles : 768;
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, w, b, z,
-                       stats, N, H, W);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, w, b,
+                       reinterpret_cast<act_t*>(z), stats, N, H, W);
     return hip_status();
 }
 
-extern "C" int yunet_dp_fwd(const YunetDP* d, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
+    if (d->z_dtype != YUNET_ACT_DTYPE && !(d->cout == 16 && d->z_dtype == YUNET_F32)) return YUNET_EINVAL;
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
     if (d->cin == 16 && d->cout == 16 && d->W >= 64 && d->H >= 32)
@@ -596,25 +636,27 @@ extern "C" int yunet_dp_fwd(const YunetDP* d, void* stream) {
     return YUNET_EINVAL;
 }
 
-extern "C" int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
-                              int C, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
+                                          int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z,
-                       *bn, out, N, H, W, C);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out), N, H, W, C);
     return hip_status();
 }
 
-extern "C" int yunet_upadd_fwd(const float* za, const YunetBN* bna, const float* zb,
-                               const YunetBN* bnb, float* out, int N, int H, int W, int C,
-                               void* stream) {
+extern "C" int ACT_SUFFIX(yunet_upadd_fwd)(const float* za, const YunetBN* bna, const float* zb,
+                                           const YunetBN* bnb, float* out, int N, int H, int W, int C,
+                                           void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
     const long long total = (long long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, za,
-                       *bna, zb, *bnb, out, N, H, W, C);
+    hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const act_t*>(za), *bna, reinterpret_cast<const act_t*>(zb), *bnb,
+                       reinterpret_cast<act_t*>(out), N, H, W, C);
     return hip_status();
 }
 
+#ifndef YUNET_ACT_BF16
 extern "C" int yunet_bn_update_running(const double* stats, float* running_mean,
                                        float* running_var, int C, int count, float momentum,
                                        void* stream) {
@@ -625,3 +667,4 @@ extern "C" int yunet_bn_update_running(const double* stats, float* running_mean,
 
 extern "C" int yunet_conv_blocks(void) { return CONV_BLOCKS; }
 extern "C" int yunet_abi_version(void) { return YUNET_ABI_VERSION; }
+#endif

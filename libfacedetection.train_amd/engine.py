@@ -214,6 +214,10 @@ class Plan:
     def __init__(self, eng, n, h, w, gmax):
         self.eng, self.n, self.h, self.w, self.gmax = eng, n, h, w, gmax
         arch, lay, fp, dev = eng.arch, eng.layout, eng.params, eng.device
+        # activation storage of this plan: fp32, or bf16 ("bf16 fwd / fp32 grads", BASELINE configs[2]):
+        # every tensor a forward kernel writes except the head output; gradients stay fp32
+        self.act_dtype = torch.bfloat16 if eng.precision == 'bf16' else torch.float32
+        self.act_flag = L.BF16 if eng.precision == 'bf16' else L.F32
         self.keep = []          # python objects that must outlive the op arrays
         self.fwd_a, self.fwd_b, self.bwd = [], [], []
         self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
@@ -419,6 +423,7 @@ class Plan:
     def _op(self, opcode, p=(), i=(), f=()):
         op = L.YunetOp()
         op.opcode = opcode
+        op.i[11] = self.act_flag          # stem / pool / upsample-add ops: activation storage type
         for k, v in enumerate(p):
             op.p[k] = v
         for k, v in enumerate(i):
@@ -442,14 +447,14 @@ class Plan:
                          count, BN_EPS)
 
     def _new_t(self, n, h, w, c, bn_name=None):
-        buf = torch.empty(n, h, w, c, device=self.eng.device, dtype=torch.float32)
+        buf = torch.empty(n, h, w, c, device=self.eng.device, dtype=self.act_dtype)
         t = _T(buf, n, h, w, c, bn=bn_name)
         return t
 
     def _grad_of(self, t):
         """(grad buffer, accumulate flag) for a consumer's backward; first writer overwrites."""
         if t.grad is None:
-            t.grad = torch.empty_like(t.buf)
+            t.grad = torch.empty(t.buf.shape, device=t.buf.device, dtype=torch.float32)   # gradients: always fp32
         acc = t.grad_written
         t.grad_written = True
         return t.grad, int(acc)
@@ -499,6 +504,8 @@ class Plan:
         ptrs = lay.unit_ptrs(fp.data, name)
         d.w_pw, d.b_pw, d.w_dw, d.b_dw = ptrs[0], ptrs[1], ptrs[2], ptrs[3]
         d.z = z
+        d.x_dtype = self.act_flag
+        d.z_dtype = self.act_flag if u['bn'] else L.F32          # the fused heads write the fp32 [N,P,16]
         bn_name = name + '.bn' if u['bn'] else None
         d.out_bn = self._bn_struct(bn_name, x.n * x.h * x.w) if bn_name else _NULL_BN
         return d, u, bn_name
@@ -611,6 +618,7 @@ class YuNetEngine:
         self.plans = {}
         self.plan = None
         self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
+        self.precision = 'fp32'         # 'fp32' | 'bf16' (activation storage + forward matrix instruction)
         self.lib = L.load()
         self._host_idx = {}
 
@@ -646,11 +654,16 @@ class YuNetEngine:
         plan.gt_boxes.view(-1, 4).index_copy_(0, lin, boxes)
         plan.gt_kps.view(-1, 15).index_copy_(0, lin, kps)
 
+    def set_precision(self, precision):
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(f"precision {precision!r}: 'fp32' or 'bf16'")
+        self.precision = precision
+
     def get_plan(self, n, h, w, max_gt):
         gmax = 64
         while gmax < max_gt:
             gmax *= 2
-        key = (n, h, w, gmax)
+        key = (n, h, w, gmax, self.precision)
         if key not in self.plans:
             if h % 32 or w % 32:
                 raise ValueError('input height/width must be multiples of 32 (reference: '

@@ -19,6 +19,21 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _act(t):
+    """(storage flag, entry-point suffix) of an activation tensor: fp32 or bf16 (BASELINE configs[2])."""
+    if t.dtype == torch.bfloat16:
+        return L.BF16, '_bf16'
+    assert t.dtype == torch.float32, 'activations are fp32 or bf16'
+    return L.F32, ''
+
+
+def _chk_act(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous(), \
+                'expected a contiguous fp32 / bf16 CUDA tensor'
+
+
 def _chk_f32(*ts):
     for t in ts:
         if t is not None:
@@ -60,13 +75,13 @@ def dp_row_width(cin, cout):
     return cout * cin + cout + cout * 9 + cout
 
 
-def stem_fwd(img, w, b, stats):
-    """img [N,3,H,W] NCHW -> raw z [N,H/2,W/2,16] NHWC; accumulates stats (fp64 [32])."""
+def stem_fwd(img, w, b, stats, dtype=torch.float32):
+    """img [N,3,H,W] NCHW -> raw z [N,H/2,W/2,16] NHWC (fp32 or bf16 storage); accumulates stats (fp64 [32])."""
     _chk_f32(img, w, b)
     n, _, h, ww = img.shape
-    z = torch.empty(n, h // 2, ww // 2, 16, device=img.device, dtype=torch.float32)
-    L.check(L.load().yunet_stem_fwd(_p(img), _p(w), _p(b), _p(z), _p(stats), n, h, ww, 16,
-                                    _stream()), 'yunet_stem_fwd')
+    z = torch.empty(n, h // 2, ww // 2, 16, device=img.device, dtype=dtype)
+    fn = getattr(L.load(), 'yunet_stem_fwd' + _act(z)[1])
+    L.check(fn(_p(img), _p(w), _p(b), _p(z), _p(stats), n, h, ww, 16, _stream()), 'yunet_stem_fwd')
     return z
 
 
@@ -77,8 +92,8 @@ def stem_bwd(img, z, dy, bn):
     width = 16 * 27 + 16
     part = torch.empty(blocks, width, device=img.device, dtype=torch.float32)
     bnc = bn.c()
-    L.check(L.load().yunet_stem_bwd(_p(img), _p(z), _p(dy), C.byref(bnc), _p(part), blocks, n, h,
-                                    w, 16, _stream()), 'yunet_stem_bwd')
+    fn = getattr(L.load(), 'yunet_stem_bwd' + _act(z)[1])
+    L.check(fn(_p(img), _p(z), _p(dy), C.byref(bnc), _p(part), blocks, n, h, w, 16, _stream()), 'yunet_stem_bwd')
     out = torch.empty(width, device=img.device, dtype=torch.float32)
     reduce_partials(part, out)
     return out[:432].view(16, 3, 3, 3), out[432:]
@@ -130,30 +145,36 @@ def _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, x_img_stride=None,
     d.w_pw, d.b_pw, d.w_dw, d.b_dw = (w_pw.data_ptr(), b_pw.data_ptr(), w_dw.data_ptr(),
                                      b_dw.data_ptr())
     d.z = z.data_ptr()
+    d.x_dtype = _act(x)[0]
+    d.z_dtype = _act(z)[0]
     return d
 
 
 def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_stride=None):
-    """ConvDPUnit forward.  x [N,H,W,Cin] raw producer output (in_bn given) or activations.
-    Returns raw z [N,H,W,Cout]; accumulates out_bn.stats when out_bn is given."""
-    _chk_f32(x, w_pw, b_pw, w_dw, b_dw)
+    """ConvDPUnit forward.  x [N,H,W,Cin] raw producer output (in_bn given) or activations, fp32 or
+    bf16 storage.  Returns raw z [N,H,W,Cout] in x's storage type (pass z to choose: the fused heads
+    write fp32); accumulates out_bn.stats when out_bn is given."""
+    _chk_f32(w_pw, b_pw, w_dw, b_dw)
+    _chk_act(x, z)
     n, h, w, _ = x.shape
     cout = w_pw.shape[0]
     if z is None:
-        z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+        z = torch.empty(n, h, w, cout, device=x.device, dtype=x.dtype)
     d = _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, z_img_stride=z_img_stride)
-    L.check(L.load().yunet_dp_fwd(C.byref(d), _stream()), 'yunet_dp_fwd')
+    L.check(getattr(L.load(), 'yunet_dp_fwd' + _act(x)[1])(C.byref(d), _stream()), 'yunet_dp_fwd')
     return z
 
 
 def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=None,
            dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True):
-    """ConvDPUnit backward.  Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw)."""
-    _chk_f32(x, w_pw, b_pw, w_dw, b_dw, dy)
+    """ConvDPUnit backward.  x, z: saved activations (fp32 or bf16); dy, dx fp32.
+    Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw)."""
+    _chk_f32(w_pw, b_pw, w_dw, b_dw, dy)
+    _chk_act(x)
     n, h, w, cin = x.shape
     cout = w_pw.shape[0]
     if dx is None and need_dx:
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     d = _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, z_img_stride=z_img_stride)
     d.dy = dy.data_ptr()
     d.dy_scale = dy_scale.data_ptr() if dy_scale is not None else None
@@ -163,7 +184,9 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
     width = dp_row_width(cin, cout)
     part = torch.empty(blocks, width, device=x.device, dtype=torch.float32)
     d.wgrad_partials, d.wgrad_blocks = part.data_ptr(), blocks
-    L.check(L.load().yunet_dp_bwd(C.byref(d), _stream()), 'yunet_dp_bwd')
+    if z.dtype != x.dtype:
+        d.z_dtype = d.x_dtype          # heads: z (the fp32 flat) is never read in backward
+    L.check(getattr(L.load(), 'yunet_dp_bwd' + _act(x)[1])(C.byref(d), _stream()), 'yunet_dp_bwd')
     out = torch.empty(width, device=x.device, dtype=torch.float32)
     reduce_partials(part, out)
     o1, o2, o3 = cout * cin, cout * cin + cout, cout * cin + cout + cout * 9
@@ -173,9 +196,9 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
 
 def pool_fwd(z, bn):
     n, h, w, c = z.shape
-    out = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)
+    out = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=z.dtype)
     bnc = bn.c()
-    L.check(L.load().yunet_pool_fwd(_p(z), C.byref(bnc), _p(out), n, h, w, c, _stream()),
+    L.check(getattr(L.load(), 'yunet_pool_fwd' + _act(z)[1])(_p(z), C.byref(bnc), _p(out), n, h, w, c, _stream()),
             'yunet_pool_fwd')
     return out
 
@@ -183,10 +206,10 @@ def pool_fwd(z, bn):
 def pool_bwd(z, bn, dy_out, dx=None, accumulate=False):
     n, h, w, c = z.shape
     if dx is None:
-        dx = torch.empty_like(z)
+        dx = torch.empty(z.shape, device=z.device, dtype=torch.float32)
     bnc = bn.c()
-    L.check(L.load().yunet_pool_bwd(_p(z), C.byref(bnc), _p(dy_out), _p(dx), int(accumulate), n, h,
-                                    w, c, _stream()), 'yunet_pool_bwd')
+    L.check(getattr(L.load(), 'yunet_pool_bwd' + _act(z)[1])(_p(z), C.byref(bnc), _p(dy_out), _p(dx), int(accumulate),
+                                                             n, h, w, c, _stream()), 'yunet_pool_bwd')
     return dx
 
 
@@ -194,19 +217,19 @@ def upadd_fwd(za, bna, zb, bnb):
     n, h, w, c = za.shape
     out = torch.empty_like(za)
     a, b = bna.c(), bnb.c()
-    L.check(L.load().yunet_upadd_fwd(_p(za), C.byref(a), _p(zb), C.byref(b), _p(out), n, h, w, c,
-                                     _stream()), 'yunet_upadd_fwd')
+    L.check(getattr(L.load(), 'yunet_upadd_fwd' + _act(za)[1])(_p(za), C.byref(a), _p(zb), C.byref(b), _p(out), n, h,
+                                                               w, c, _stream()), 'yunet_upadd_fwd')
     return out
 
 
 def upadd_bwd(za, bna, zb, bnb, dout, dxa=None, acc_a=False, dxb=None, acc_b=False):
     n, h, w, c = za.shape
-    dxa = torch.empty_like(za) if dxa is None else dxa
-    dxb = torch.empty_like(zb) if dxb is None else dxb
+    dxa = torch.empty(za.shape, device=za.device, dtype=torch.float32) if dxa is None else dxa
+    dxb = torch.empty(zb.shape, device=zb.device, dtype=torch.float32) if dxb is None else dxb
     a, b = bna.c(), bnb.c()
-    L.check(L.load().yunet_upadd_bwd(_p(za), C.byref(a), _p(zb), C.byref(b), _p(dout), _p(dxa),
-                                     int(acc_a), _p(dxb), int(acc_b), n, h, w, c, _stream()),
-            'yunet_upadd_bwd')
+    L.check(getattr(L.load(), 'yunet_upadd_bwd' + _act(za)[1])(_p(za), C.byref(a), _p(zb), C.byref(b), _p(dout),
+                                                               _p(dxa), int(acc_a), _p(dxb), int(acc_b), n, h, w, c,
+                                                               _stream()), 'yunet_upadd_bwd')
     return dxa, dxb
 
 

@@ -241,6 +241,17 @@ class YuNet(nn.Module):
             loss_kps_weight=hd.loss_kps.loss_weight, kps_beta=hd.loss_kps.beta,
             center_radius=hd.assigner.center_radius if hd.assigner is not None else 2.5)
 
+    def set_precision(self, precision):
+        """'fp32' (default) or 'bf16': bf16 activation storage + bf16 matrix instruction in the forward
+        pointwise convs, fp32 gradients / master weights / loss step (BASELINE.json configs[2]; the
+        reference's analogue is fp16 training, mmdet/apis/train.py:181-185 -> Fp16OptimizerHook)."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(f"precision {precision!r}: 'fp32' or 'bf16'")
+        self._precision = precision
+        self.fp16_enabled = precision != 'fp32'
+        if self.engine is not None:
+            self.engine.set_precision(precision)
+
     def set_data_parallel(self, world_size, group=None):
         """Called by YuNetDistributedDataParallel: one process per GPU, RCCL collectives."""
         self._world, self._group = world_size, group
@@ -258,6 +269,7 @@ class YuNet(nn.Module):
         """(Re)create the engine on `device` and re-point every parameter/buffer into it."""
         sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
         eng = YuNetEngine(self.arch(), device, self._world, self._group)
+        eng.set_precision(getattr(self, '_precision', 'fp32'))
         eng.params.load_state_dict(sd)
         fp = eng.params
         for name, p in self.named_parameters():

@@ -1,0 +1,220 @@
+"""-m gpu: the bf16 mode (BASELINE.json configs[2] "bf16 fwd / fp32 grads"): activations stored as
+bf16, gradients / head output / parameters fp32.
+
+Kernel level: every kernel of the bf16 build against the fp32 build fed the SAME (bf16-representable)
+inputs -- the arithmetic is identical, only the stored activations are rounded, so outputs that are
+activations agree to one bf16 rounding (2^-8 relative) and everything else (BN sums, gradients) to
+fp32 rounding.  Step level, the STATED tolerance of the mode against the fp32 path and the CPU oracle
+(measured first with tools/ubench/bf16_probe.py on randomly initialised networks, whose SimOTA costs
+are nearly degenerate -- every prior predicts IoU ~ 0.3 -- so 0.4 % activation noise reorders many
+candidates; that is the hard case for assignment agreement):
+  * SimOTA: >= 70 % of the positive priors identical (measured 76 - 88 %), positive count within 5 %,
+    mean matched IoU within 2 %,
+  * the four losses within 5 % relative (measured <= 3 %),
+  * parameter gradients: cosine similarity with the fp32 path >= 0.90 at bs 8 - 16 (0.93 - 0.955;
+    0.985 at bs 64),
+  * head outputs within 20 % of the fp32 path's in max-norm over all 33 k x 16 values (0.06 - 0.13),
+  * the same 12 SGD iterations (lr 1e-4) descend together: every iteration's loss within 10 %."""
+import pytest
+import torch
+
+import yunet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def K():
+    import yunet_amd.kernels as k
+    return k
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def stats_of(z):
+    z = z.double().reshape(-1, z.shape[-1])
+    return torch.cat([z.sum(0), (z * z).sum(0)]).contiguous()
+
+
+def unit(cin, cout, g):
+    return (torch.randn(cout, cin, generator=g).to(DEV) * (2.0 / (cin + cout)) ** 0.5,
+            torch.randn(cout, generator=g).to(DEV) * 0.1, torch.randn(cout, 9, generator=g).to(DEV) * 0.3,
+            torch.randn(cout, generator=g).to(DEV) * 0.1)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (16, 64), (32, 64), (64, 64), (64, 16)])
+@pytest.mark.parametrize('shape', [(3, 20, 40), (2, 64, 96), (9, 10, 10)])
+def test_dp_unit_bf16_vs_fp32_build(cin, cout, shape):
+    k = K()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x16 = bf(torch.randn(n, h, w, cin, generator=g) * 2 + 0.5).to(DEV)
+    x32 = x16.float()
+    wp, bp, wd, bd = unit(cin, cout, g)
+    gi, bi = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * .2).to(DEV)
+    go, bo = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * .2).to(DEV)
+    has_bn = not (cin == 64 and cout == 16)
+    res = {}
+    for tag, x in (('f32', x32), ('bf16', x16)):
+        in_bn = k.BN(stats_of(x32), gi, bi, n * h * w, bstats=torch.zeros(2 * cin, dtype=torch.float64, device=DEV))
+        ost = torch.zeros(2 * cout, dtype=torch.float64, device=DEV)
+        out_bn = k.BN(ost, go, bo, n * h * w) if has_bn else None
+        z = None if has_bn else torch.empty(n, h, w, cout, device=DEV)            # heads write fp32
+        z = k.dp_fwd(x, wp, bp, wd, bd, in_bn, out_bn, z=z)
+        res[tag] = (z, ost.clone(), in_bn)
+    z32, st32, _ = res['f32']
+    z16, st16, _ = res['bf16']
+    assert z16.dtype == (torch.bfloat16 if has_bn else torch.float32)
+    scale = float(z32.abs().max())
+    if cin % 32 == 0:
+        # 32 / 64 input channels: the bf16 build runs the pointwise GEMM on the bf16 matrix instruction with
+        # a = bf16(relu(bn(x))) and bf16(W1), fp32 accumulation -- compare with exactly that in fp64
+        import torch.nn.functional as F
+        xc = x32.double().cpu().permute(0, 3, 1, 2)
+        mean = xc.mean(dim=(0, 2, 3), keepdim=True)
+        var = xc.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        a = F.relu((xc - mean) / torch.sqrt(var + 1e-5) * gi.double().cpu().view(1, -1, 1, 1) + bi.double().cpu().view(1, -1, 1, 1))
+        a = a.float().to(torch.bfloat16).double()
+        wq = wp.cpu().to(torch.bfloat16).double().view(cout, cin, 1, 1)
+        p = F.conv2d(a, wq, bp.double().cpu())
+        zr = F.conv2d(p, wd.double().cpu().view(cout, 1, 3, 3), bd.double().cpu(), padding=1, groups=cout).permute(0, 2, 3, 1)
+        tol = (2.0 ** -7 if has_bn else 3e-3) * float(zr.abs().max())    # bf16 storage: 2^-8 rounding (+ a flipped a here and there)
+        assert float((z16.double().cpu() - zr).abs().max()) <= tol
+        if has_bn:
+            assert float((st16.cpu() - stats_of(zr)).abs().max()) <= 3e-3 * float(stats_of(zr).abs().max())
+    elif has_bn:
+        assert torch.equal(z16, bf(z32)), 'bf16 output is not the RNE rounding of the fp32 output'
+        assert float((st16 - st32).abs().max()) <= 1e-9 * float(st32.abs().max())    # sums of the UNROUNDED values
+    else:
+        assert float((z16 - z32).abs().max()) <= 1e-6 * scale
+    # backward: saved activations bf16, gradients fp32 -- identical arithmetic to the fp32 build on the
+    # widened tensors
+    dy = torch.randn(n, h, w, cout, generator=g).to(DEV)
+    out = {}
+    for tag, x, z in (('f32', x32, z16.float()), ('bf16', x16, z16)):
+        in_bn = k.BN(stats_of(x32), gi, bi, n * h * w, bstats=torch.zeros(2 * cin, dtype=torch.float64, device=DEV))
+        out_bn = None
+        dys = None
+        if has_bn:
+            zz = z16.float()
+            bst = torch.randn(2 * cout, generator=torch.Generator().manual_seed(1)).double().to(DEV)
+            out_bn = k.BN(stats_of(zz), go, bo, n * h * w, bstats=bst)
+        else:
+            dys = torch.ones(cout, device=DEV)
+        r = k.dp_bwd(x, wp, bp, wd, bd, z, dy, in_bn, out_bn, dy_scale=dys)
+        out[tag] = [t.clone() for t in r] + [in_bn.bstats.clone()]
+    torch.cuda.synchronize()
+    for a, b in zip(out['f32'], out['bf16']):
+        assert a.dtype == b.dtype and float((a.double() - b.double()).abs().max()) <= 1e-6 * float(a.abs().max() + 1e-30)
+
+
+def test_stem_pool_upadd_bf16_vs_fp32_build():
+    k = K()
+    g = torch.Generator().manual_seed(4)
+    n, h, w = 3, 64, 96
+    img = (torch.rand(n, 3, h, w, generator=g) * 255).to(DEV)
+    wt, b = (torch.randn(16, 3, 3, 3, generator=g) * 0.05).to(DEV), (torch.randn(16, generator=g) * 0.1).to(DEV)
+    s32, s16 = torch.zeros(32, dtype=torch.float64, device=DEV), torch.zeros(32, dtype=torch.float64, device=DEV)
+    z32 = k.stem_fwd(img, wt, b, s32)
+    z16 = k.stem_fwd(img, wt, b, s16, dtype=torch.bfloat16)
+    assert z16.dtype == torch.bfloat16 and torch.equal(z16, bf(z32)) and torch.allclose(s16, s32, rtol=1e-9)
+    gam, bet = (torch.rand(16, generator=g) + 0.5).to(DEV), (torch.randn(16, generator=g) * .2).to(DEV)
+    dy = torch.randn(z32.shape, generator=g).to(DEV)
+    bst = torch.randn(32, generator=g).double().to(DEV)
+    zz = z16.float()
+    r32 = k.stem_bwd(img, zz, dy, k.BN(stats_of(zz), gam, bet, n * h * w // 4, bstats=bst))
+    r16 = k.stem_bwd(img, z16, dy, k.BN(stats_of(zz), gam, bet, n * h * w // 4, bstats=bst))
+    for a, c in zip(r32, r16):
+        assert float((a - c).abs().max()) <= 1e-6 * float(a.abs().max())
+    # pool
+    c = 64
+    za16 = bf(torch.randn(n, 12, 20, c, generator=g) * 2).to(DEV)
+    ga, ba = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * .3).to(DEV)
+
+    def bn_for(z16_, cnt):
+        return k.BN(stats_of(z16_.float()), ga, ba, cnt, bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
+    p32 = k.pool_fwd(za16.float(), bn_for(za16, n * 240))
+    p16 = k.pool_fwd(za16, bn_for(za16, n * 240))
+    assert p16.dtype == torch.bfloat16 and torch.equal(p16, bf(p32))
+    dyo = torch.randn(p32.shape, generator=g).to(DEV)
+    b32, b16 = bn_for(za16, n * 240), bn_for(za16, n * 240)
+    d32, d16 = k.pool_bwd(za16.float(), b32, dyo), k.pool_bwd(za16, b16, dyo)
+    assert d16.dtype == torch.float32 and torch.equal(d32, d16) and torch.allclose(b32.bstats, b16.bstats, rtol=1e-12)
+    # upsample-add
+    zb16 = bf(torch.randn(n, 6, 10, c, generator=g) * 2).to(DEV)
+    u32 = k.upadd_fwd(za16.float(), bn_for(za16, n * 240), zb16.float(), bn_for(zb16, n * 60))
+    u16 = k.upadd_fwd(za16, bn_for(za16, n * 240), zb16, bn_for(zb16, n * 60))
+    assert torch.equal(u16, bf(u32))
+    dout = torch.randn(u32.shape, generator=g).to(DEV)
+    a32 = k.upadd_bwd(za16.float(), bn_for(za16, n * 240), zb16.float(), bn_for(zb16, n * 60), dout)
+    a16 = k.upadd_bwd(za16, bn_for(za16, n * 240), zb16, bn_for(zb16, n * 60), dout)
+    assert torch.equal(a32[0], a16[0]) and torch.equal(a32[1], a16[1])
+
+
+def _model(kind, sd, precision):
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile(f'configs/yunet_{kind}.py')
+    m = yunet_amd.build_detector(cfg.model)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).train()
+    m.set_precision(precision)
+    return m
+
+
+@pytest.mark.parametrize('kind,h,n', [('n', 320, 16), ('s', 160, 8)])
+def test_bf16_step_vs_fp32_step_and_oracle(kind, h, n):
+    import yunet_amd.synthetic as S
+    arch = O.yunet_arch(kind)
+    sd = O.init_state(arch, seed=21)
+    b = S.make_batch(n, h, h, 77)
+    out = {}
+    for prec in ('fp32', 'bf16'):
+        m = _model(kind, sd, prec)
+        losses = m.forward_train(**S.to_device(b, DEV))
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        plan = m.engine.plan
+        assert plan.act_dtype == (torch.bfloat16 if prec == 'bf16' else torch.float32)
+        out[prec] = dict(l={k: float(v) for k, v in losses.items()}, gi=plan.gt_inds.cpu().clone(),
+                         g=m.engine.params.grad.detach().cpu().clone(), flat=plan.flat.cpu().clone())
+    lv, _, aux = O.train_step(b, {k: v.clone() for k, v in sd.items()}, arch)
+    a, c = out['fp32'], out['bf16']
+    pos = (a['gi'] > 0) | (c['gi'] > 0)
+    agree = float(((a['gi'] == c['gi']) & pos).sum()) / max(1, int(pos.sum()))
+    assert agree >= 0.70, agree
+    pos_o = (aux['gt_inds'] > 0) | (c['gi'] > 0)
+    assert float(((aux['gt_inds'].int() == c['gi']) & pos_o).sum()) / max(1, int(pos_o.sum())) >= 0.70
+    na, nc = int((a['gi'] > 0).sum()), int((c['gi'] > 0).sum())
+    assert abs(na - nc) <= 0.05 * na, (na, nc)
+    for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
+        assert abs(c['l'][k] - a['l'][k]) <= 5e-2 * abs(a['l'][k]) + 1e-6, (k, c['l'][k], a['l'][k])
+        assert abs(c['l'][k] - lv[k]) <= 5e-2 * abs(lv[k]) + 1e-6, (k, c['l'][k], lv[k])
+    cos = float((a['g'] * c['g']).sum() / (a['g'].norm() * c['g'].norm()))
+    assert cos >= 0.90, cos
+    assert float((c['flat'] - a['flat']).abs().max()) <= 0.2 * float(a['flat'].abs().max())
+
+
+def test_bf16_training_tracks_fp32_training():
+    import yunet_amd.synthetic as S
+    from yunet_amd.optim import FusedSGD
+    arch = O.yunet_arch('s')
+    sd = O.init_state(arch, seed=5)
+    final = {}
+    for prec in ('fp32', 'bf16'):
+        m = _model('s', sd, prec)
+        opt = FusedSGD(m, lr=1e-4, momentum=0.9, weight_decay=5e-4)     # small steps: a smooth, comparable descent
+        hist = []
+        for it in range(12):
+            batch = S.to_device(S.make_batch(8, 160, 160, S.batch_seed(0, it % 2)), DEV)
+            o = m.train_step(batch, opt)
+            opt.zero_grad()
+            o['loss'].backward()
+            opt.step()
+            hist.append(float(o['log_vars']['loss']))
+        final[prec] = hist
+    a, c = final['fp32'], final['bf16']
+    assert sum(a[-2:]) < sum(a[:2]) and sum(c[-2:]) < sum(c[:2]), final
+    for x, y in zip(a, c):                         # every iteration of the two runs within 10 %
+        assert abs(x - y) <= 0.10 * x, final
