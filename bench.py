@@ -252,29 +252,35 @@ def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
     cores = effective_cores()
     torch.set_num_threads(cores)
     arch = O.yunet_arch(kind)
-    sd = O.init_state(arch, seed=0)
-    opt = O.SGD(lr=1e-5)
-    bs = 32
-    b = S.make_batch(bs, size, size, seed)
-    sync = (lambda: None)
-    if device != 'cpu':
-        dev = torch.device(device)
-        sd = {k: v.to(dev) for k, v in sd.items()}
-        b = dict(b, img=b['img'].to(dev), gt_bboxes=[t.to(dev) for t in b['gt_bboxes']],
-                 gt_labels=[t.to(dev) for t in b['gt_labels']],
-                 gt_keypointss=[t.to(dev) for t in b['gt_keypointss']])
-        sync = torch.cuda.synchronize
-    O.train_step(b, sd, arch, opt)          # warm-up (MIOpen kernel selection on the GPU)
-    sync()
-    t0 = time.time()
-    iters = 0
-    while iters < 2 or (time.time() - t0 < budget_s and iters < 50):
-        O.train_step(b, sd, arch, opt)
-        iters += 1
-    sync()
-    dt = time.time() - t0
+    sync = (lambda: None) if device == 'cpu' else torch.cuda.synchronize
+    # Two batch sizes, the better one is reported: on the MI355X host torch's CPU convolutions fall off a
+    # cliff between bs 16 and bs 32 (measured 129 vs 33 img/s on 16 threads, tools/ubench/cpu_probe.py),
+    # and the baseline should be the CPU's best case
+    runs = []
+    for bs in ((16, 32) if device == 'cpu' else (32,)):
+        sd = O.init_state(arch, seed=0)
+        opt = O.SGD(lr=1e-5)
+        b = S.make_batch(bs, size, size, seed)
+        if device != 'cpu':
+            dev = torch.device(device)
+            sd = {k: v.to(dev) for k, v in sd.items()}
+            b = dict(b, img=b['img'].to(dev), gt_bboxes=[t.to(dev) for t in b['gt_bboxes']],
+                     gt_labels=[t.to(dev) for t in b['gt_labels']],
+                     gt_keypointss=[t.to(dev) for t in b['gt_keypointss']])
+        O.train_step(b, sd, arch, opt)          # warm-up (MIOpen kernel selection on the GPU)
+        sync()
+        t0 = time.time()
+        iters = 0
+        while iters < 2 or (time.time() - t0 < budget_s / (2 if device == 'cpu' else 1) and iters < 50):
+            O.train_step(b, sd, arch, opt)
+            iters += 1
+        sync()
+        runs.append((bs * iters / (time.time() - t0), bs, iters))
+    rate, bs, iters = max(runs)
+    dt = bs * iters / rate
+    others = '; '.join(f'bs {b_}: {r_:.1f} img/s' for r_, b_, _ in runs)
     what = (f'oracle/yunet_oracle.py train_step (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} '
-            f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch fp32')
+            f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch fp32 ({others})')
     if device != 'cpu':
         return dict(value=round(bs * iters / dt, 2), unit='images/sec', kind='port',
                     sample=what + ', eager PyTorch-ROCm ops on cuda:0 (un-accelerated GPU row)')
