@@ -15,6 +15,12 @@
 
 #include "common.h"
 
+// 1: forward pointwise GEMM of the 32 / 64-channel units as a three-way bf16 split (fp32-accurate);
+// 0: exact-fp32 matrix instruction (A/B builds, tools/ubench)
+#ifndef YUNET_FWD_SPLIT3
+#define YUNET_FWD_SPLIT3 1
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------- stem
@@ -194,7 +200,11 @@ struct DpGeom {
     static constexpr size_t BUF_BYTES = (size_t)MP * LS * 4;
     static constexpr size_t RED_BYTES = 256 * 8 * 8;
     static constexpr size_t BUFB = BUF_BYTES > RED_BYTES ? BUF_BYTES : RED_BYTES;
-    static constexpr size_t SMEM = BUFB + (size_t)(COUT * WS + 9 * COUT + COUT + 3 * CIN) * 4;
+    // pointwise weights: fp32 [COUT][WS], or (split-bf16 forward, 32 / 64 input channels) three bf16
+    // planes [COUT][CIN] with XOR-swizzled 16-byte chunks
+    static constexpr size_t W1_FP32 = (size_t)COUT * WS * 4, W1_SPLIT = (size_t)3 * COUT * CIN * 2;
+    static constexpr size_t W1_BYTES = (CIN % 32 == 0 && W1_SPLIT > W1_FP32) ? W1_SPLIT : W1_FP32;
+    static constexpr size_t SMEM = BUFB + W1_BYTES + (size_t)(9 * COUT + COUT + 3 * CIN) * 4;
     static_assert(PG % TW == 0 && TH % RG == 0, "tile / thread mapping");
     static_assert(256 % C4I == 0, "load mapping");
 };
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* buf = reinterpret_cast<float*>(smem_raw);
     float* s_w1 = reinterpret_cast<float*>(smem_raw + G::BUFB);   // [COUT][WS]
-    float* s_w2 = s_w1 + COUT * G::WS;                            // [9][COUT]
+    float* s_w2 = reinterpret_cast<float*>(smem_raw + G::BUFB + G::W1_BYTES);   // [9][COUT]
     float* s_b2 = s_w2 + 9 * COUT;                                // [COUT]
     float* s_coef = s_b2 + COUT;                                  // mean | scale | beta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -268,7 +278,24 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     constexpr bool BF16_MMA = YUNET_ACT_DTYPE == YUNET_BF16 && CIN % 32 == 0;
     constexpr int WSB = CIN + 8;                                      // bf16 weight row stride (elements)
     __bf16* s_w1b = reinterpret_cast<__bf16*>(s_w1);                  // [COUT][WSB], inside the fp32-sized block
-    if constexpr (BF16_MMA) {
+    // fp32 build, 32 / 64 input channels: three-way bf16 split of BOTH operands, x = h + m + l EXACTLY
+    // (3 x 8 significand bits), six bf16 MFMAs per product block (hh, hm, mh, mm, hl, lh; the dropped
+    // ml, lm, ll terms are <= 2^-24 relative): fp32-accurate at 6/16 of the fp32 matrix time.
+    constexpr bool SPLIT3 = YUNET_ACT_DTYPE == YUNET_F32 && CIN % 32 == 0 && YUNET_FWD_SPLIT3;
+    constexpr int NCH = CIN / 8;                                      // 16-byte chunks per weight row
+    __bf16* s_w1p = reinterpret_cast<__bf16*>(s_w1);                  // planes h | m | l, each [COUT][CIN], swizzled
+    if constexpr (SPLIT3) {
+        for (int i = tid; i < COUT * CIN; i += 256) {
+            const int co = i / CIN, ci = i % CIN;
+            const float w = d.w_pw[i];
+            const __bf16 h = (__bf16)w;
+            const float r1 = w - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const __bf16 l = (__bf16)(r1 - (float)m);
+            const int at = co * CIN + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
+            s_w1p[at] = h; s_w1p[COUT * CIN + at] = m; s_w1p[2 * COUT * CIN + at] = l;
+        }
+    } else if constexpr (BF16_MMA) {
         for (int i = tid; i < COUT * CIN; i += 256) s_w1b[(i / CIN) * WSB + (i % CIN)] = (__bf16)d.w_pw[i];
     } else {
         for (int i = tid; i < COUT * CIN; i += 256) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
@@ -331,11 +358,68 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
         // the registers are free again: fetch the next tile while this one is computed
         if (t + (int)gridDim.x < ntiles && !(abl & 8)) issue(t + gridDim.x);
         // ---- pw: pointwise 1x1 on the matrix cores, in place ------------------------------------
+        // epilogue of one 16-pixel M tile: bias, zero outside the image, back to LDS in place
+        auto store_p = [&](int mt, const f32x4 (&acc)[G::NT]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hp = mt * 16 + 4 * g + r;
+            const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            // the depthwise conv zero-pads the POINTWISE OUTPUT: outside the image p = 0,
+            // not pw(0)+bias (SURVEY.md 7 "zero-halo trap")
+            int pn, py, px;
+            const bool in = hp < G::HP && (PACKED ? pk_locate(pk, y, x, pn, py, px)
+                                                 : (y >= 0 && y < H && x >= 0 && x < W));
+#pragma unroll
+            for (int nt = 0; nt < G::NT; ++nt)
+                buf[hp * G::LS + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
+        }
+        };
         for (int mt = wid; mt < ((abl & 1) ? 0 : G::MT); mt += 4) {
             f32x4 acc[G::NT];
 #pragma unroll
             for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF16_MMA) {
+            if constexpr (SPLIT3) {
+                // (measured: one M tile at a time, 0.240 ms at 80x80; the wave's three tiles together with
+                //  shared weight fragments, 0.320 ms -- the long read / convert prologue no longer overlaps
+                //  the matrix instructions of the previous tile)
+                typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+                const float* arow = buf + (mt * 16 + l15) * G::LS + 8 * g;
+#pragma unroll
+                for (int kb = 0; kb < CIN / 32; ++kb) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(arow + 32 * kb);
+                    const float4 x1 = *reinterpret_cast<const float4*>(arow + 32 * kb + 4);
+                    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    u32x4 ah, am, al;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a0 = xs[2 * q], a1 = xs[2 * q + 1];
+                        const unsigned hb = pack_bf16x2(a0, a1);
+                        const float r0 = a0 - __uint_as_float(hb << 16), r1 = a1 - __uint_as_float(hb & 0xffff0000u);
+                        const unsigned mb = pack_bf16x2(r0, r1);
+                        const unsigned lb = pack_bf16x2(r0 - __uint_as_float(mb << 16), r1 - __uint_as_float(mb & 0xffff0000u));
+                        ah[q] = hb; am[q] = mb; al[q] = lb;
+                    }
+                    const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, ah), Am = __builtin_bit_cast(bf16x8_t, am),
+                                   Al = __builtin_bit_cast(bf16x8_t, al);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) {
+                        const int co = nt * 16 + l15;
+                        const __bf16* bp = s_w1p + co * CIN + (((4 * kb + g) ^ (co & (NCH - 1))) << 3);
+                        const bf16x8_t Bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp));
+                        const bf16x8_t Bm = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + COUT * CIN));
+                        const bf16x8_t Bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + 2 * COUT * CIN));
+                        f32x4 c = acc[nt];                       // small terms first
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+                        acc[nt] = c;
+                    }
+                }
+            } else if constexpr (BF16_MMA) {
                 // lane group g supplies input channels 32*kb + 8g .. +7 on both sides
                 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
                 const float* arow = buf + (mt * 16 + l15) * G::LS + 8 * g;
@@ -392,20 +476,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                 __builtin_amdgcn_sched_barrier(0);
             }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hp = mt * 16 + 4 * g + r;
-                const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                // the depthwise conv zero-pads the POINTWISE OUTPUT: outside the image p = 0,
-                // not pw(0)+bias (SURVEY.md 7 "zero-halo trap")
-                int pn, py, px;
-                const bool in = hp < G::HP && (PACKED ? pk_locate(pk, y, x, pn, py, px)
-                                                     : (y >= 0 && y < H && x >= 0 && x < W));
-#pragma unroll
-                for (int nt = 0; nt < G::NT; ++nt)
-                    buf[hp * G::LS + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
-            }
+            store_p(mt, acc);
         }
         __syncthreads();
         if (prof) { const unsigned long long c = clock64(); pc[1] += c - c0; c0 = c; }

@@ -36,7 +36,7 @@ typedef int (*blocks_fn)(int, int, int, int, int);
 struct Variant {
     std::string name, env_k, env_v;
     void* h;
-    dp_fn bwd;
+    dp_fn bwd, fwd;
     blocks_fn blocks;
 };
 
@@ -95,7 +95,8 @@ int main(int argc, char** argv) {
         }
         v.bwd = (dp_fn)dlsym(v.h, "yunet_dp_bwd");
         v.blocks = (blocks_fn)dlsym(v.h, "yunet_dp_bwd_blocks");
-        if (!v.bwd || !v.blocks) return 2;
+        v.fwd = (dp_fn)dlsym(v.h, "yunet_dp_fwd");
+        if (!v.bwd || !v.blocks || !v.fwd) return 2;
         vs.push_back(v);
     }
     struct Shape { int ci, co, h, w; };
@@ -157,6 +158,56 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dbsi, 2 * ci * 8));
         const int width = co * ci + co + co * 9 + co;
         std::vector<double> ref_dx, ref_w, ref_b;
+        if (getenv("FWD")) {
+            // FWD=1: the FORWARD kernel instead (z and the output BN sums against the first variant)
+            float* dzo;
+            CK(hipMalloc(&dzo, px * co * 4));
+            double* dst;
+            CK(hipMalloc(&dst, 2 * co * 8));
+            std::vector<double> rz, rs;
+            for (size_t vi = 0; vi < vs.size(); ++vi) {
+                Variant& v = vs[vi];
+                if (!v.env_k.empty()) setenv(v.env_k.c_str(), v.env_v.c_str(), 1);
+                YunetDP d;
+                memset(&d, 0, sizeof(d));
+                d.N = N; d.H = H; d.W = W; d.cin = ci; d.cout = co;
+                d.in_transform = YUNET_T_BNRELU; d.out_has_bn = 1;
+                d.x_img_stride = (int64_t)H * W * ci; d.z_img_stride = (int64_t)H * W * co;
+                d.x = dx_x;
+                d.in_bn = YunetBN{dsin, nullptr, dgi, dbi, (int32_t)px, 1e-5f};
+                d.w_pw = dwp; d.b_pw = dbp; d.w_dw = dwd; d.b_dw = dbd;
+                d.z = dzo;
+                d.out_bn = YunetBN{dst, nullptr, dgo, dbo, (int32_t)px, 1e-5f};
+                CK(hipMemsetAsync(dst, 0, 2 * co * 8, st));
+                int rc = v.fwd(&d, st);
+                CK(hipStreamSynchronize(st));
+                if (rc != 0) { printf("%-40s fwd rc=%d\n", v.name.c_str(), rc); continue; }
+                std::vector<float> hz(px * co);
+                std::vector<double> hs(2 * co);
+                CK(hipMemcpy(hz.data(), dzo, hz.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<double> vz(hz.begin(), hz.end());
+                for (int i = 0; i < 3; ++i) v.fwd(&d, st);
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < reps; ++i) v.fwd(&d, st);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                const double gbs = (double)px * (ci + co) * 4 / (ms * 1e-3) / 1e9;
+                if (vi == 0) {
+                    rz = vz; rs = hs;
+                    printf("%dx%d %d->%d N=%d  fwd %-40s %8.4f ms %7.1f GB/s  (yardstick)\n", H, W, ci, co, N, v.name.c_str(), ms, gbs);
+                } else {
+                    printf("%dx%d %d->%d N=%d  fwd %-40s %8.4f ms %7.1f GB/s  err z %.2e stats %.2e\n", H, W, ci, co, N,
+                           v.name.c_str(), ms, gbs, rel(vz, rz, 0, vz.size()), rel(hs, rs, 0, hs.size()));
+                }
+                if (!v.env_k.empty()) unsetenv(v.env_k.c_str());
+            }
+            fflush(stdout);
+            hipFree(dzo); hipFree(dst);
+        } else
         for (size_t vi = 0; vi < vs.size(); ++vi) {
             Variant& v = vs[vi];
             if (!v.env_k.empty()) setenv(v.env_k.c_str(), v.env_v.c_str(), 1);
