@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv
 #   3. PMC passes (FETCH_SIZE / WRITE_SIZE, separately)  -> gpurun_out/rNN_pmc_{fetch,write}.csv
 #      over tools/kbench.py on the dominant kernels + a calibration copy of known size
-R=${1:-r01}
+R=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -33,4 +33,14 @@ for c in MfmaUtil VALUBusy LdsUtil LDSBankConflict; do
   for f in $(find /tmp/util_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_util_$c.csv; UT="$UT $OUT/${R}_util_$c.csv"; done
 done
 python $GRAFT_REPO_ROOT/tools/pmc_mean.py $OUT/${R}_util.json $UT
+#   5. the second bench line (bf16 activations / bf16 forward matrix instruction, fp32 gradients)
+cd $GRAFT_REPO_ROOT
+timeout 300 python bench.py --dtype bf16 --steps 30 --warmup 10 --no-cpu-baseline --no-gpu-eager 2>/dev/null | tail -1 > $OUT/${R}_bench_bf16.json
+#   6. torch-free kernel A/B at sustained clocks: round-1 backward / forward builds vs this round's
+if [ -f tools/ubench/libyunet_r1.so ]; then
+  REPS=1000 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r1.so libfacedetection.train_amd/libyunet_hip.so:YUNET_BWD_FP32MMA=1 \
+      libfacedetection.train_amd/libyunet_hip.so > $OUT/${R}_bwd_ab.log 2>&1
+  FWD=1 REPS=1000 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r1.so libfacedetection.train_amd/libyunet_hip.so \
+      > $OUT/${R}_fwd_ab.log 2>&1
+fi
 ls -la $OUT | tail -8
