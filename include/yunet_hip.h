@@ -171,7 +171,10 @@ typedef struct YunetLevels {
  * gt_count [N].  Outputs: gt_inds [N,P] int32 (1-based, 0 = background),
  * labels [N,P] int32 (-1 background) or NULL, max_overlaps [N,P] (-1e5 background),
  * img_stats [N,2] = {num_pos, sum of kps weights}.  scratch: [N,P,8] fp32.
- * Ties at the k-th cost are broken towards the lowest prior index. */
+ * Ties at the k-th cost are broken towards the lowest prior index.
+ * Limits (YUNET_EINVAL beyond them): P <= 65535 priors per image (16-bit candidate indices in LDS:
+ * a 1760x1760 training crop; the shipped configs train at 320 - 640, P <= 8400) and
+ * Gmax*sizeof(GT) + 8*P bytes <= 150 KB of LDS (Gmax = 64: P <= 18.7 k). */
 int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
                  const int32_t* gt_labels, const int32_t* gt_count, const YunetLevels* lv,
                  int N, int P, int Gmax, float center_radius, int32_t* gt_inds,

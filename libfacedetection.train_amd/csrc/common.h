@@ -178,9 +178,8 @@ static inline PackGeom dp_pack_geom(int N, int H, int W) {
 static inline bool dp_use_pack(int N, int H, int W, int cin, int cout) {
     return cin == 64 && (cout == 64 || cout == 16) && dp_pack_geom(N, H, W).on;
 }
-// backward: measured per-launch on MI355X the packed 64->16 unit wins (25.9 -> 21.5 us at 10x10),
-// the packed 64->64 one does not yet (its canvas mapping pushes the kernel into scratch), so the
-// latter keeps the per-image tiling
+// backward: the same decision as forward for both packed variants (64->16 and 64->64; the latter went
+// scratch-free with the per-tile validity byte map)
 static inline bool dp_use_pack_bwd(int N, int H, int W, int cin, int cout) {
     return dp_use_pack(N, H, W, cin, cout);
 }
