@@ -9,7 +9,10 @@ One "step" = one full training iteration of YuNet_n on a 256-image 320x320 synth
 WIDER-Face-shaped batch per GPU (BASELINE.json configs[1]): the reference's per-iteration
 sequence model.train_step -> zero_grad -> loss.backward -> optimizer.step
 (forward + SimOTA + 4 losses + backward + gradient all-reduce + SGD), fp32, inputs already
-resident in HBM.  Rank 0 prints ONE JSON line.
+resident in HBM.  Rank 0 prints ONE JSON line.  Weights: the trained-checkpoint-like fixture
+tests/golden/yunet_n_synth_trained.pth with structured synthetic faces (SimOTA dynamic_k 7-9, SURVEY 8d);
+--weights init = random initialisation on noise images.  --dtype bf16 = the second line (configs[2]);
+--gpus N without a launcher re-executes under torch.distributed.run.
 
 Extra objects on that line (N=1 only):
   roofline     -- the kernel with the largest share of the step, timed per launch with
@@ -49,6 +52,10 @@ def parse():
     p.add_argument('--no-gpu-eager', action='store_true',
                    help='skip the un-accelerated-GPU row (the oracle\'s eager torch ops on cuda:0)')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--weights', default='trained', choices=['trained', 'init'],
+                   help="trained: tests/golden/yunet_n_synth_trained.pth (2000 SGD iterations on structured synthetic "
+                        "faces) + structured batches, so that SimOTA runs with dynamic_k of 7-9 like a real checkpoint; "
+                        "init: random initialisation on noise images (dynamic_k = 1 for 90 %% of the GTs)")
     p.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                    help="f32: the headline line (BASELINE configs[1]); bf16: activation storage + forward matrix "
                         "instruction in bf16, fp32 gradients / weights (configs[2]) -- a SECOND line, never the headline")
@@ -360,9 +367,22 @@ def main():
     opt = FusedSGD(model, lr=cfg.optimizer['lr'] * 0.001, momentum=cfg.optimizer['momentum'],
                    weight_decay=cfg.optimizer['weight_decay'])   # lr at warm-up iteration 0
 
+    # trained-checkpoint-like weights: only for the architecture / size the fixture was trained on
+    fixture = os.path.join(ROOT, 'tests', 'golden', 'yunet_n_synth_trained.pth')
+    trained = a.weights == 'trained' and a.kind == 'n' and os.path.exists(fixture)
+    if trained:
+        model.load_state_dict(torch.load(fixture, map_location='cpu', weights_only=False)['state_dict'], strict=True)
+
     # synthetic batches, resident in HBM before the timed region
-    pool = [S.to_device(S.make_batch(a.batch, a.size, a.size, S.batch_seed(rank, i)), dev)
-            for i in range(2)]
+    def make(i):
+        if not trained:
+            return S.to_device(S.make_batch(a.batch, a.size, a.size, S.batch_seed(rank, i)), dev)
+        b = S.make_batch(a.batch, a.size, a.size, S.batch_seed(rank, i), with_img=False)
+        gen = torch.Generator(device=dev).manual_seed(S.batch_seed(rank, i))
+        img = torch.rand(a.batch, 3, a.size, a.size, generator=gen, device=dev) * 255.0
+        b['img'] = S.render_faces(img, b['gt_bboxes'], b['gt_keypointss'])      # face patterns over the noise
+        return S.to_device(b, dev)
+    pool = [make(i) for i in range(2)]
 
     def step(i):
         out = wrapped.train_step(pool[i % len(pool)], opt)
@@ -404,13 +424,16 @@ def main():
             'value': round(world * a.batch * a.steps / dt, 1), 'unit': 'images/sec',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+            'data': 'synthetic' if not trained else 'synthetic (face patterns painted over noise at the GT boxes)',
             'config': {'workload': f'YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU full training '
                                    'step (fwd + SimOTA + losses + bwd + grad all-reduce + SGD), '
                                    'synthetic WIDER-Face-shaped batches, ' +
                                    ('fp32' if a.dtype == 'f32' else 'bf16 activations + bf16 forward matrix instruction, fp32 gradients / weights'),
                        'parallelism': f'dp{world}', 'global_batch': world * a.batch},
             'final_loss': round(last_loss, 4),
+            'weights': ('tests/golden/yunet_n_synth_trained.pth + structured synthetic faces' if trained
+                        else 'random init + noise images'),
             'per_rank_images_per_sec': [round(a.batch * a.steps / t, 1) for t in per_rank],
             'dist': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world,
                      'collectives_per_step': 0 if world == 1 else 3,
