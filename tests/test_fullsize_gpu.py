@@ -220,9 +220,12 @@ def test_full_step_vs_oracle(kind, h, n, seed):
         work64 = dict(sd64)
         work64.update(leaf64)
         flat64 = O.flatten_preds(*O.conv_stack_forward(b['img'].double(), work64, arch, True))
+        # one fp64 backward with the GPU's d loss/d flat; a second one with the oracle's own only when the two
+        # assignments differ somewhere (identical assignments: the two upstream gradients agree to 2e-5, far
+        # inside the tolerance, and the second pass costs a quarter of this test's minutes)
         g64_g = torch.autograd.grad((flat64 * dflat_g.double()).sum(), [leaf64[k] for k in keys],
-                                    retain_graph=True)
-        g64_o = torch.autograd.grad((flat64 * dflat_o.double()).sum(), [leaf64[k] for k in keys])
+                                    retain_graph=bool(diff))
+        g64_o = torch.autograd.grad((flat64 * dflat_o.double()).sum(), [leaf64[k] for k in keys]) if diff else g64_g
         del flat64
         scale = max(float(v.abs().max()) for v in g64_g)
         worst = (0.0, None)
