@@ -8,7 +8,7 @@ lr_config = dict(policy='step', warmup='linear', warmup_iters=1500, warmup_ratio
                  step=[50 * lr_mult, 68 * lr_mult])
 runner = dict(type='EpochBasedRunner', max_epochs=80 * lr_mult)
 checkpoint_config = dict(interval=80)
-log_config = dict(interval=50, hooks=[dict(type='TextLoggerHook')])
+log_config = dict(interval=50, hooks=[dict(type='TextLoggerHook'), dict(type='TensorboardLoggerHook')])
 dist_params = dict(backend='nccl')     # RCCL on ROCm
 log_level = 'INFO'
 load_from = None

@@ -51,6 +51,8 @@ class Config(ConfigDict):
             node = self
             parts = key.split('.')
             for p in parts[:-1]:
+                if p not in node or not isinstance(node[p], dict):
+                    node[p] = ConfigDict()          # mmcv creates the intermediate dicts (e.g. fp16.loss_scale=512.)
                 node = node[p]
             node[parts[-1]] = value
 

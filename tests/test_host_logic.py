@@ -219,7 +219,7 @@ def test_bench_byte_model_matches_survey_figures():
     pw_flops = sum(bench.op_flops(op, L) for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
     assert pw_flops / n / 2 / 1e6 == pytest.approx(135.6 * 0.765, rel=0.03)
     # the committed PMC table is found and keyed by the names bench.py prints
-    traffic, src = bench.pmc_traffic('dp_bwd_kernel<64,64,8,16,false>')
+    traffic, src = bench.pmc_traffic('dp_bwd_kernel<64,64,8,16,false,1>')
     assert traffic is not None and traffic > 1e8 and src.endswith('_pmc_traffic.json')
 
 
@@ -251,3 +251,12 @@ def test_bbox_mapping_back_matches_reference():
             assert torch.equal(got, want)
             if ref is not None:
                 assert torch.equal(got, ref.bbox_mapping_back(b, (480, 640, 3), sf, flip, direction))
+
+
+def test_cfg_options_create_missing_sections():
+    """--cfg-options fp16.loss_scale=512. on a config without an fp16 section (mmcv Config.merge_from_dict)."""
+    import yunet_amd
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'yunet_s.py'))
+    assert cfg.get('fp16') is None
+    cfg.merge_from_dict({'fp16.loss_scale': 512.0, 'data.samples_per_gpu': 16, 'a.b.c': 1})
+    assert cfg.fp16.loss_scale == 512.0 and cfg.data.samples_per_gpu == 16 and cfg.a.b.c == 1
