@@ -52,6 +52,8 @@ def parse():
     p.add_argument('--no-gpu-eager', action='store_true',
                    help='skip the un-accelerated-GPU row (the oracle\'s eager torch ops on cuda:0)')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-live-traffic', action='store_true',
+                   help='roofline.traffic from the committed profiles/ table instead of two live rocprofv3 --pmc passes')
     p.add_argument('--weights', default='trained', choices=['trained', 'init'],
                    help="trained: tests/golden/yunet_n_synth_trained.pth (2000 SGD iterations on structured synthetic "
                         "faces) + structured batches, so that SimOTA runs with dynamic_k of 7-9 like a real checkpoint; "
@@ -147,6 +149,45 @@ def pmc_traffic(kernel):
     except Exception:
         pass
     return None, None
+
+
+def live_traffic(kernel, a):
+    """HBM bytes per launch of `kernel`, measured NOW: two child passes of this same bench step
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as
+    MI355X_MICROARCH.md prescribes), reduced by tools/pmc_summary.per_kernel with the same unit and
+    gfx950 corrections as the committed table (KiB -> bytes, FETCH_SIZE x 2).  None when rocprofv3
+    is missing or a pass fails -- the caller then falls back to the committed table."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, 'tools'))
+    try:
+        from pmc_summary import per_kernel
+    finally:
+        sys.path.pop(0)
+    key = kernel.replace(' ', '')
+    kib = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix='yunet_pmc_')
+        try:
+            subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '-o', 'p',
+                            '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1',
+                            '--no-cpu-baseline', '--no-roofline', '--kind', a.kind, '--size', str(a.size),
+                            '--batch', str(a.batch), '--weights', a.weights, '--dtype', a.dtype],
+                           capture_output=True, timeout=240, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
+            csvs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith('counter_collection.csv')]
+            if not csvs or key not in (tab := per_kernel(csvs[0])):
+                return None
+            kib[counter] = tab[key][1]
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return int(2 * kib['FETCH_SIZE'] * 1024 + kib['WRITE_SIZE'] * 1024)
 
 
 def op_name(op, L):
@@ -447,10 +488,16 @@ def main():
         per_launch_ms = top['ms'] / top['launches']
         achieved = top['bytes'] / top['launches'] / (per_launch_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(name)
+        committed = traffic
+        if not a.no_live_traffic:
+            live = live_traffic(name, a)
+            if live:
+                traffic, traffic_src = live, 'live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench step'
         tflops = top['flops'] / top['launches'] / (per_launch_ms * 1e-3) / 1e12
         res['roofline'] = {
             'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'traffic_committed_profile': committed,
             'kernel': name,
             # the same kernel against the exact-fp32 matrix-core ceiling (v_mfma_f32_16x16x4_f32:
             # 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz); algorithmic GEMM FLOPs only
