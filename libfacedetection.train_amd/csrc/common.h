@@ -81,6 +81,20 @@ __device__ __forceinline__ void act_st4(act_t* p, const float4 v) {
     *reinterpret_cast<act_raw4*>(p) = act_pack(v);
 }
 
+// Persistent tile kernels: hardware hands workgroup ids to the 8 XCDs round-robin (id % 8), so with
+// "tile = blockIdx.x + k * gridDim.x" the spatial neighbours of a tile (which share its halo rows /
+// columns) always run on OTHER XCDs and the halo is fetched once per L2.  first_tile() renumbers the
+// workgroups so that each XCD walks a contiguous run of tiles: neighbours are in flight on the same
+// XCD at the same time and the second reader of a halo line hits that XCD's L2.
+#ifndef YUNET_XCD_REMAP
+#define YUNET_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int first_tile() {
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    if (YUNET_XCD_REMAP && (g & 7) == 0) return (b & 7) * (g >> 3) + (b >> 3);
+    return b;
+}
+
 // D = A(16x4) * B(4x16) + C, exact fp32 (v_mfma_f32_16x16x4_f32).
 // lane l supplies A[row = l&15][k = l>>4], B[k = l>>4][col = l&15];
 // D/C: col = l&15, row = (l>>4)*4 + reg.
@@ -156,7 +170,7 @@ struct PackGeom {
 };
 static inline PackGeom make_pack(int N, int H, int W) {
     PackGeom g;
-    g.on = (H <= 20 && W <= 20 && N >= 4) ? 1 : 0;
+    g.on = (H <= 20 && W <= 20 && N >= 4) ? 1 : 0;     // 40x40 measured slower packed (r2)
     g.H = H; g.W = W; g.N = N;
     g.ph = H + 1; g.pw = W + 1;
     g.R = N < 16 ? N : 16;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     // the first tile's global loads go out BEFORE the weights / coefficients are staged: the HBM
     // latency of a cold start runs under the prologue
     using All = std::integral_constant<int, -1>;
-    int t = blockIdx.x;
+    int t = first_tile();
     if (t < ntiles) issue(t, All{});
 
     if constexpr (GEMM == 1) {
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 
     const int tiles_x = (Wo + SB_TW - 1) / SB_TW, tiles_y = (Ho + SB_TH - 1) / SB_TH;
     const int ntiles = N * tiles_x * tiles_y;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int t = first_tile(); t < ntiles; t += gridDim.x) {
         const int n = t / (tiles_x * tiles_y);
         const int r = t - n * tiles_x * tiles_y;
         const int y0 = (r / tiles_x) * SB_TH, x0 = (r % tiles_x) * SB_TW;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             ld[k] = *reinterpret_cast<const float4*>(&v);
         }
     };
-    int t = blockIdx.x;
+    int t = first_tile();
     if (t < ntiles) issue(t);
     for (; t < ntiles; t += gridDim.x) {
         const int n = t / (tiles_x * tiles_y);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
         }
     };
     // the first tile's loads go out before the weights are staged (cold-start latency under the prologue)
-    int t = blockIdx.x;
+    int t = first_tile();
     if (t < ntiles) issue(t);
 
     // bf16 build, 32 / 64 input channels: the pointwise GEMM runs on v_mfma_f32_16x16x32_bf16 (16x the

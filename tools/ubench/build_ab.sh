@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds the torch-free backward A/B harness and variant libraries of libyunet_hip.so:
 #   tools/ubench/build_ab.sh [NAME "EXTRA_HIPCC_FLAGS"] ...
-# -> tools/ubench/bwd_ab.bin, and for every NAME a libyunet_NAME.so next to it whose conv_bwd.o was
+# -> tools/ubench/bwd_ab.bin, and for every NAME a libyunet_NAME.so next to it whose conv_bwd.o / conv_fwd.o were
 #    compiled with the extra flags (the other objects are shared with the product build).
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -12,8 +12,11 @@ make -C $CSRC -j8 >/dev/null
 $HIPCC --offload-arch=gfx950 -O2 $ROOT/tools/ubench/bwd_ab.cpp -o $ROOT/tools/ubench/bwd_ab.bin -ldl
 while [ $# -ge 2 ]; do
   name=$1; extra=$2; shift 2
-  $HIPCC $FLAGS $extra -c $CSRC/conv_bwd.hip -o /tmp/conv_bwd_$name.o
-  $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o $CSRC/conv_fwd.o /tmp/conv_bwd_$name.o \
-      $CSRC/augment.o $CSRC/detect.o $CSRC/api.o -o $ROOT/tools/ubench/libyunet_$name.so
+  $HIPCC $FLAGS $extra -c $CSRC/conv_bwd.hip -o /tmp/conv_bwd_$name.o &
+  $HIPCC $FLAGS $extra -c $CSRC/conv_fwd.hip -o /tmp/conv_fwd_$name.o &
+  wait
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o /tmp/conv_fwd_$name.o /tmp/conv_bwd_$name.o \
+      $CSRC/conv_fwd_bf16.o $CSRC/conv_bwd_bf16.o $CSRC/augment.o $CSRC/detect.o $CSRC/api.o \
+      -o $ROOT/tools/ubench/libyunet_$name.so
   echo built libyunet_$name.so
 done
