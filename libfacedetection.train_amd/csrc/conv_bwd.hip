@@ -83,7 +83,7 @@ struct BwdGeom {
     static constexpr int PAR_F = W1_F + 9 * COUT + 7 * COUT + 5 * CIN + W1T_F + 4 * CIN + IP / 4;   // w1 | w2 | out-bn | in-bn | w1^T | fp64 sums | validity bytes
     static_assert(GEMM == 0 || (CIN % 32 == 0 && COUT % 32 == 0 && (IP / KSPLIT) % 32 == 0), "bf16 MFMA: K in blocks of 32");
     static constexpr int WROW = COUT * CIN + COUT + COUT * 9 + COUT;  // partial row width
-    static constexpr size_t RED1 = (size_t)BWD_THREADS * 16 * 4;      // dW2/db reduction (3 passes)
+    static constexpr size_t RED1 = ((size_t)BWD_WAVES / NGRP * COUT * CIN + (size_t)BWD_THREADS * 24) * 4;   // flush area: dW1 K-slice planes + dW2/db records
     static constexpr size_t WORK = (size_t)WORK_F * 4;
     static constexpr size_t WORKB = WORK > RED1 ? WORK : RED1;
     static constexpr size_t SMEM = WORKB + (size_t)PAR_F * 4;
@@ -853,56 +853,50 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     const unsigned long long prof_t1 = __builtin_readcyclecounter();
 #endif
     float* row = d.wgrad_partials + (size_t)blockIdx.x * G::WROW;
-    // (a) dW1: MFMA accumulators -> LDS [COUT][CIN] (summing the K slices in a fixed order)
-    float* s_gw1 = sm;  // COUT*CIN floats, fits in the work area
-    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) s_gw1[i] = 0.0f;
-    __syncthreads();
-    for (int ks = 0; ks < G::KSPLIT; ++ks) {
-        if (w1_kslice == ks) {
-#pragma unroll
-            for (int j = 0; j < G::MB; ++j)
-#pragma unroll
-                for (int i = 0; i < G::NB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s_gw1[(w1_co0 + G::NB * l15 + i) * CIN + w1_ci0 + G::MB * (4 * g + r) + j] +=
-                            gw1[j * G::NB + i][r];
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) row[i] = s_gw1[i];
-    __syncthreads();
-    // (b) db1 | dW2 | db2: reduce the per-thread accumulators over the pixel groups, in three
-    //     passes of <= 16 floats per thread (keeps the LDS footprint at 32 KB)
+    // Every wave parks its dW1 tiles in the LDS plane of its K slice and every thread its
+    // dW2 | db1 | db2 accumulators in a record (two passes of 6 / 5 float4: 11 at once do not fit next to
+    // the planes with 512 threads); the sums over K slices / pixel groups are taken in a fixed order
+    // while the row is written.  Three barriers in all.
+    float* s_gw1 = sm;                                   // [KSPLIT][COUT][CIN]
+    float* red = sm + G::KSPLIT * COUT * CIN;            // [BWD_THREADS][24]
     {
-        float* red = sm;  // [BWD_THREADS][16]
-        float* my = red + tid * 16;
+        float* pl = s_gw1 + w1_kslice * COUT * CIN;
 #pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int j = 0; j < G::MB; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 v = make_float4(0, 0, 0, 0);
-                if (pass < 2) v = gw2[pass * 4 + j];
-                else if (j == 0) v = gw2[8];
-                else if (j == 1) v = gb1;
-                else if (j == 2) v = gb2;
-                my[j * 4 + 0] = v.x; my[j * 4 + 1] = v.y; my[j * 4 + 2] = v.z; my[j * 4 + 3] = v.w;
-            }
-            __syncthreads();
-            const int nslot = pass < 2 ? 4 : 3;
-            for (int o = tid; o < COUT * nslot; o += BWD_THREADS) {
-                const int c = o / nslot, j = o - c * nslot;
-                const int q = c >> 2, e = c & 3;
-                float v = 0.0f;
-                for (int p = 0; p < G::PG; ++p) v += red[(p * G::C4O + q) * 16 + j * 4 + e];
-                if (pass < 2) row[COUT * CIN + COUT + c * 9 + pass * 4 + j] = v;
-                else if (j == 0) row[COUT * CIN + COUT + c * 9 + 8] = v;
-                else if (j == 1) row[COUT * CIN + c] = v;
-                else row[COUT * CIN + COUT + COUT * 9 + c] = v;
-            }
-            __syncthreads();
-        }
+            for (int i = 0; i < G::NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pl[(w1_co0 + G::NB * l15 + i) * CIN + w1_ci0 + G::MB * (4 * g + r) + j] = gw1[j * G::NB + i][r];
     }
+    float4* my = reinterpret_cast<float4*>(red + tid * 24);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) my[k] = gw2[k];
+    __syncthreads();
+    for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
+        float v = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < G::KSPLIT; ++ks) v += s_gw1[ks * COUT * CIN + i];
+        row[i] = v;
+    }
+    // record slot k of pass ps: dW2 tap 6*ps + k, then db1, db2
+    auto reduce_pass = [&](int ps, int nslot) {
+        for (int o = tid; o < COUT * nslot; o += BWD_THREADS) {
+            const int c = o / nslot, k = o - c * nslot;
+            const int q = c >> 2, e = c & 3;
+            float v = 0.0f;
+            for (int p = 0; p < G::PG; ++p) v += red[(p * G::C4O + q) * 24 + k * 4 + e];
+            const int slot = ps * 6 + k;
+            if (slot < 9) row[COUT * CIN + COUT + c * 9 + slot] = v;
+            else if (slot == 9) row[COUT * CIN + c] = v;
+            else row[COUT * CIN + COUT + COUT * 9 + c] = v;
+        }
+    };
+    reduce_pass(0, 6);
+    __syncthreads();
+    my[0] = gw2[6]; my[1] = gw2[7]; my[2] = gw2[8]; my[3] = gb1; my[4] = gb2;
+    __syncthreads();
+    reduce_pass(1, 5);
     // (c) BN-backward sums of the producer: one global fp64 atomic per channel
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
 #ifdef DP_BWD_PROF
