@@ -145,7 +145,7 @@ __device__ __forceinline__ f32x4 mfma3(const Split8& a, const u32x4 bh, const u3
     return c;
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED, int GEMM = 0>
+template <int CIN, int COUT, int TH, int TW, bool PACKED, int GEMM = 0, bool POOLDY = false>
 __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, const PackGeom pk) {
     using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int H = d.H, W = d.W;
-    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
+    const bool bn_in = d.in_transform != YUNET_T_IDENTITY;      // BNRELU, or POOLED (mask + sums from x itself)
     const bool bn_out = d.out_has_bn != 0;
     // The input transform is applied branch-free where MFMA operands are read: with the identity
     // coefficients (mean 0, scale 1, beta 0) and a floor of -inf it returns its argument exactly,
@@ -203,6 +203,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     float4 pdy[G::NDZ];
     act_raw4 pz[G::NDZ], px[G::NX];          // saved activations: storage type of this build (fp32 | bf16)
     unsigned okmask = 0;
+    // POOLDY (YunetDP.dy_pool_idx): the unit's output feeds max_pool2d and nothing else.  A halo slot then
+    // loads the gradient of ITS pooled element and that element's argmax bytes (4 channels = one dword);
+    // the stage keeps the gradient where the slot is the window maximum.  posmask: window position
+    // 2*(y&1) + (x&1) of every slot, two bits each.
+    static_assert(!(POOLDY && PACKED), "pooled dy: unpacked levels only");
+    static_assert(!POOLDY || G::NDZ <= 16, "posmask holds 16 slots");
+    unsigned pid[POOLDY ? G::NDZ : 1];
+    unsigned posmask = 0;
+    const int Wq = W >> 1;
+    const unsigned pooledbytes = (unsigned)((H >> 1) * Wq * COUT) * 4u;
     // dy / dx are fp32 in every build; z and x are activations
     const unsigned dybytes = (unsigned)(H * W * COUT) * 4u, zbytes = (unsigned)(H * W * COUT) * ACT_B;
     const unsigned xbytes = (unsigned)(H * W * CIN) * ACT_B, dxbytes = (unsigned)(H * W * CIN) * 4u;
@@ -223,12 +233,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * ACT_B : xbytes;
         const size_t zbase = PACKED ? (size_t)0 : (size_t)n * d.z_img_stride;
         const size_t xbase = PACKED ? (size_t)0 : (size_t)n * d.x_img_stride;
-        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy) + zbase, 0, dyrange, 0x00020000);
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.dy) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : zbase), 0, POOLDY ? pooledbytes : dyrange, 0x00020000);
+        const auto r_id = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(d.dy_pool_idx) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0,
+            POOLDY ? pooledbytes / 4u : 0u, 0x00020000);
         const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xrange, 0x00020000);
-        if (PART <= 0) okmask = 0;
+        if (PART <= 0) { okmask = 0; posmask = 0; }
 #pragma unroll
         for (int i = 0; i < G::NDZ; ++i) {
             if (PART >= 0 && PART != 1 + (3 * i) / G::NDZ) continue;
@@ -246,8 +260,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 eo = (unsigned)((y * W + x) * COUT + och4 * 4);
             }
             okmask |= ok ? (1u << i) : 0u;
-            const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dyrange, 0, 0);
-            pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+            if constexpr (POOLDY) {
+                const unsigned eq = (unsigned)(((y >> 1) * Wq + (x >> 1)) * COUT + och4 * 4);   // pooled element
+                posmask |= (unsigned)(((y & 1) << 1) | (x & 1)) << (2 * i);
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+                pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
+            } else {
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dyrange, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+            }
             pz[i] = act_raw4{};
             if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zrange);
             // packed: finish one slot's address arithmetic before the next one starts (otherwise
@@ -324,7 +346,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         }
     }
     for (int c = tid; c < CIN; c += BWD_THREADS) {
-        if (bn_in) {
+        if (d.in_transform == YUNET_T_POOLED) {
+            // x = max_pool2d(relu(bn(z))) is used as it is (mean 0, scale 1, beta 0); ReLU mask x > 0;
+            // xhat at the window maximum from x itself: ((x - 0) - beta) * (1 / gamma)
+            const float gm = d.in_bn.gamma[c];
+            s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f;
+            s_ci[3 * CIN + c] = gm != 0.0f ? 1.0f / gm : 0.0f;
+            s_ci[4 * CIN + c] = d.in_bn.beta[c];
+        } else if (bn_in) {
             const BNCoef k = bn_coef(d.in_bn, CIN, c);
             s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
             s_ci[3 * CIN + c] = k.invstd; s_ci[4 * CIN + c] = k.mean_lo;
@@ -387,7 +416,16 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             for (int i = 0; i < G::NDZ; ++i) {
                 const int hp = hp0 + PSTEP * i;
                 if ((i + 1) * PSTEP <= G::HP || hp < G::HP) {
-                    const float4 dy = pdy[i], z = act_unpack(pz[i]);
+                    float4 dy = pdy[i];
+                    const float4 z = act_unpack(pz[i]);
+                    if constexpr (POOLDY) {
+                        // max_pool2d backward: the pooled gradient reaches the window maximum only
+                        const unsigned id = pid[i], pos = (posmask >> (2 * i)) & 3u;
+                        dy.x = (id & 0xffu) == pos ? dy.x : 0.0f;
+                        dy.y = ((id >> 8) & 0xffu) == pos ? dy.y : 0.0f;
+                        dy.z = ((id >> 16) & 0xffu) == pos ? dy.z : 0.0f;
+                        dy.w = (id >> 24) == pos ? dy.w : 0.0f;
+                    }
                     float4 v;
                     if (bn_out) {
                         // zero padding of dz: a slot outside the image loaded dy = z = 0, which the
@@ -904,12 +942,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #endif
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0, bool POOLDY = false>
 int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
@@ -921,7 +959,7 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
+    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
                        stream, *d, pk);
     return hip_status();
 }
@@ -1304,6 +1342,7 @@ static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
 }
 #ifdef YUNET_ACT_BF16
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
+extern "C" int yunet_dp_bwd_pooled_dy_ok(int N, int H, int W, int cin, int cout);
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W);
 #else
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
@@ -1313,6 +1352,12 @@ extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
                                 ? (long long)((pk.CW + tw - 1) / tw) * ((pk.CH + th - 1) / th)
                                   : (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
     return (int)(tiles < DP_BWD_MAX_BLOCKS ? tiles : DP_BWD_MAX_BLOCKS);
+}
+extern "C" int yunet_dp_bwd_pooled_dy_ok(int N, int H, int W, int cin, int cout) {
+    if ((H & 1) || (W & 1)) return 0;
+    if (cin == 16 && cout == 16) return dp_bwd_big_tile(H, W, cin, cout) ? 1 : 0;
+    if (cin == 64 && cout == 64) return dp_use_pack_bwd(N, H, W, cin, cout) ? 0 : 1;
+    return 0;
 }
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W) {
     const long long tiles = (long long)N * ((W / 2 + SB_TW - 1) / SB_TW) * ((H / 2 + SB_TH - 1) / SB_TH);
@@ -1326,6 +1371,14 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (!d->wgrad_partials ||
         d->wgrad_blocks != yunet_dp_bwd_blocks(d->N, d->H, d->W, d->cin, d->cout))
         return YUNET_EINVAL;   // the partial buffer must have exactly the rows the grid writes
+    if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU && d->in_transform != YUNET_T_POOLED)
+        return YUNET_EINVAL;
+    if (d->dy_pool_idx) {
+        // dy is the pooled gradient + argmax bytes (max_pool2d backward while staging)
+        if (!yunet_dp_bwd_pooled_dy_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
+        if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
+        return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
+    }
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
     if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))

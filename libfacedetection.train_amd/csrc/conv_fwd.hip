@@ -592,7 +592,8 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
 // ------------------------------------------------------------------- pool / upsample-add
 // one thread = one float4 of channels of one OUTPUT pixel
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__ z, YunetBN bn,
-                                                       act_t* __restrict__ out, int N, int H, int W,
+                                                       act_t* __restrict__ out,
+                                                       unsigned* __restrict__ argmax, int N, int H, int W,
                                                        int C) {
     const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
     const long long total = (long long)N * Ho * Wo * C4;
@@ -607,18 +608,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__
         const int ox = (int)(pix % Wo);
         pix /= Wo;
         const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
-        float4 m = make_float4(0, 0, 0, 0);  // relu output >= 0
+        float m[4] = {0.f, 0.f, 0.f, 0.f};  // relu output >= 0
+        unsigned am = 0;                     // one byte per channel: window position 2*dy + dx of the first maximum
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
+            const float y[4] = {bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta), bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta),
+                                bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta), bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta)};
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
-                m.x = fmaxf(m.x, bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta));
-                m.y = fmaxf(m.y, bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta));
-                m.z = fmaxf(m.z, bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta));
-                m.w = fmaxf(m.w, bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta));
-            }
-        act_st4(out + e * 4, m);
+            for (int i = 0; i < 4; ++i)
+                if (y[i] > m[i]) { m[i] = y[i]; am = (am & ~(0xffu << (8 * i))) | ((unsigned)j << (8 * i)); }
+        }
+        act_st4(out + e * 4, make_float4(m[0], m[1], m[2], m[3]));
+        if (argmax) argmax[e] = am;
     }
 }
 
@@ -707,13 +709,19 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     return YUNET_EINVAL;
 }
 
-extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
-                                          int C, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_pool_fwd_argmax)(const float* z, const YunetBN* bn, float* out, uint8_t* argmax,
+                                                 int N, int H, int W, int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    if (reinterpret_cast<uintptr_t>(argmax) & 3) return YUNET_EINVAL;     // written one channel quad (4 bytes) at a time
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out), N, H, W, C);
+                       reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out),
+                       reinterpret_cast<unsigned*>(argmax), N, H, W, C);
     return hip_status();
+}
+extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
+                                          int C, void* stream) {
+    return ACT_SUFFIX(yunet_pool_fwd_argmax)(z, bn, out, nullptr, N, H, W, C, stream);
 }
 
 extern "C" int ACT_SUFFIX(yunet_upadd_fwd)(const float* za, const YunetBN* bna, const float* zb,

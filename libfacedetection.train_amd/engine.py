@@ -16,6 +16,7 @@ PyTorch supplies device memory, streams and torch.distributed only.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -192,6 +193,8 @@ class _T:
         self.img_stride = img_stride if img_stride is not None else h * w * c
         self.grad = None
         self.grad_written = False
+        self.pooled_into = None     # (pooled tensor, argmax bytes) when max_pool2d is this tensor's only consumer
+        self.pool_of = None         # the tensor this one is the fused max_pool2d of
 
 
 class _BNRef:
@@ -219,6 +222,7 @@ class Plan:
         self.act_dtype = torch.bfloat16 if eng.precision == 'bf16' else torch.float32
         self.act_flag = L.BF16 if eng.precision == 'bf16' else L.F32
         self.keep = []          # python objects that must outlive the op arrays
+        self.producer = {}      # id(tensor) -> (cin, cout) of the ConvDPUnit that wrote it
         self.fwd_a, self.fwd_b, self.bwd = [], [], []
         self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
         self.tensors = {}       # unit name -> (input _T, output _T): introspection / debugging
@@ -266,7 +270,8 @@ class Plan:
             if i in arch['out_idx']:
                 taps.append(cur)
             if i in arch['downsample_idx']:
-                cur = self._pool(cur)
+                # the pool is the stage output's only consumer unless the stage is also tapped by the neck
+                cur = self._pool(cur, sole_consumer=i not in arch['out_idx'])
         feats = list(taps)
         for i in range(len(feats) - 1, 0, -1):
             feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
@@ -513,6 +518,7 @@ class Plan:
     def _dp(self, x, name):
         u = self.eng.layout.units[name]
         z = self._new_t(x.n, x.h, x.w, u['cout'], bn_name=name + '.bn')
+        self.producer[id(z)] = (u['cin'], u['cout'])
         self._dp_node(x, name, z.buf.data_ptr(), None, z)
         self.tensors[name] = (x, z)
         return z
@@ -535,7 +541,14 @@ class Plan:
 
         def bwd():
             d2, _, _ = self._dp_desc(x, name, zptr, z_img_stride)
-            if zt is not None:
+            if zt is not None and zt.pooled_into is not None:
+                # fused max_pool2d backward: dy = the pooled gradient its consumer wrote + argmax bytes
+                out, idx = zt.pooled_into
+                assert out.grad is not None, f'{name}: pooled output has no gradient'
+                d2.dy = out.grad.data_ptr()
+                d2.dy_pool_idx = idx.data_ptr()
+                d2.dy_scale = None
+            elif zt is not None:
                 assert zt.grad is not None, f'{name}: output has no gradient'
                 d2.dy = zt.grad.data_ptr()
                 d2.dy_scale = None
@@ -545,6 +558,13 @@ class Plan:
             gx, acc = self._grad_of(x)
             d2.dx = gx.data_ptr()
             d2.accumulate_dx = acc
+            if x.pool_of is not None:
+                # x = max_pool2d(relu(bn(src))): this unit masks dx with x > 0 and accumulates the BN-backward
+                # sums of src's BatchNorm from x itself (YUNET_T_POOLED); src's backward then reads dx + argmax
+                src = x.pool_of
+                assert acc == 0, 'a fused pool output has one consumer'
+                d2.in_transform = L.T_POOLED
+                d2.in_bn = self._bn_struct(src.bn, src.n * src.h * src.w)
             d2.wgrad_partials, d2.wgrad_blocks = part.data_ptr(), blocks
             op = self._op(L.OP_DP_BWD)
             op.dp = d2
@@ -552,13 +572,25 @@ class Plan:
             self.reduce_jobs.append((part.data_ptr(), gptr, blocks, width, 0))
         self.bwd_nodes.append(bwd)
 
-    def _pool(self, x):
+    def _pool(self, x, sole_consumer=False):
         out = self._new_t(x.n, x.h // 2, x.w // 2, x.c, bn_name=None)
         cnt = x.n * x.h * x.w
-        op = self._op(L.OP_POOL_FWD, p=[x.buf.data_ptr(), out.buf.data_ptr()],
+        # Fused backward: when the pool is the only consumer of x and the producing unit has a
+        # pooled-dy build, no full-size gradient of x exists -- pool_fwd records the argmax bytes, the
+        # pool's consumer writes the masked pooled gradient + the BN sums, the producer expands it on load.
+        prod = self.producer.get(id(x))
+        fuse = bool(sole_consumer and prod is not None and not os.environ.get('YUNET_NO_POOL_FUSION') and
+                    L.load().yunet_dp_bwd_pooled_dy_ok(x.n, x.h, x.w, prod[0], prod[1]))
+        idx = torch.empty(x.n, x.h // 2, x.w // 2, x.c, device=self.eng.device, dtype=torch.uint8) if fuse else None
+        op = self._op(L.OP_POOL_FWD, p=[x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if fuse else None],
                       i=[x.n, x.h, x.w, x.c])
         op.bn[0] = self._bn_struct(x.bn, cnt)
         self.fwd_a.append(op)
+        if fuse:
+            self.keep.append(idx)
+            x.pooled_into = (out, idx)
+            out.pool_of = x
+            return out
 
         def bwd():
             gx, acc = self._grad_of(x)

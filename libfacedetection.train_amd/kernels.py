@@ -166,9 +166,13 @@ def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_str
 
 
 def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=None,
-           dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True):
+           dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True, pooled_input=False,
+           dy_pool_idx=None):
     """ConvDPUnit backward.  x, z: saved activations (fp32 or bf16); dy, dx fp32.
-    Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw)."""
+    Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw).
+    pooled_input: x is max_pool2d(relu(bn(src)), 2) and in_bn the BatchNorm of src (YUNET_T_POOLED:
+    dx gets the ReLU mask, in_bn.bstats the BN-backward sums of src).  dy_pool_idx: dy is the pooled
+    gradient [N,H/2,W/2,cout] and dy_pool_idx the argmax bytes of pool_fwd(..., argmax=True)."""
     _chk_f32(w_pw, b_pw, w_dw, b_dw, dy)
     _chk_act(x)
     n, h, w, cin = x.shape
@@ -180,6 +184,12 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
     d.dy_scale = dy_scale.data_ptr() if dy_scale is not None else None
     d.dx = dx.data_ptr() if dx is not None else None
     d.accumulate_dx = int(accumulate_dx)
+    if pooled_input:
+        d.in_transform = L.T_POOLED
+    if dy_pool_idx is not None:
+        assert dy_pool_idx.dtype == torch.uint8 and tuple(dy_pool_idx.shape) == (n, h // 2, w // 2, cout)
+        assert tuple(dy.shape) == (n, h // 2, w // 2, cout)
+        d.dy_pool_idx = dy_pool_idx.data_ptr()
     blocks = dp_grid(n, h, w, cin, cout)
     width = dp_row_width(cin, cout)
     part = torch.empty(blocks, width, device=x.device, dtype=torch.float32)
@@ -194,13 +204,15 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
             out[o3:])
 
 
-def pool_fwd(z, bn):
+def pool_fwd(z, bn, argmax=False):
+    """max_pool2d(relu(bn(z)), 2); argmax=True also returns the uint8 window positions (2*dy + dx)."""
     n, h, w, c = z.shape
     out = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=z.dtype)
+    idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8) if argmax else None
     bnc = bn.c()
-    L.check(getattr(L.load(), 'yunet_pool_fwd' + _act(z)[1])(_p(z), C.byref(bnc), _p(out), n, h, w, c, _stream()),
-            'yunet_pool_fwd')
-    return out
+    L.check(getattr(L.load(), 'yunet_pool_fwd_argmax' + _act(z)[1])(_p(z), C.byref(bnc), _p(out), _p(idx) if argmax else None,
+                                                                    n, h, w, c, _stream()), 'yunet_pool_fwd_argmax')
+    return (out, idx) if argmax else out
 
 
 def pool_bwd(z, bn, dy_out, dx=None, accumulate=False):
