@@ -98,9 +98,9 @@ def op_bytes(op, L):
         px = d.N * d.H * d.W
         xb = 2 if d.x_dtype == L.BF16 else 4
         zb = 2 if d.z_dtype == L.BF16 else 4
-        if oc == L.OP_DP_FWD:
-            return px * (d.cin * xb + d.cout * zb)
-        if d.dy_pool_idx:       # fused max_pool2d backward: dy is the pooled gradient (1/4 of the pixels) + argmax bytes
+        if oc == L.OP_DP_FWD:       # (+ the pooled winners and their position bytes when the pooling is fused)
+            return px * (d.cin * xb + d.cout * zb) + ((px // 4) * d.cout * (zb + 1) if d.pool_out else 0)
+        if d.pool_idx:          # fused max_pool2d backward: dy is the pooled gradient (1/4 of the pixels) + position bytes
             return px * (d.cin * xb + d.cin * 4) + (px // 4) * d.cout * 5
         return px * (d.cin * xb + d.cin * 4 + d.cout * 4)
     ab = 2 if op.i[11] == L.BF16 else 4
@@ -111,9 +111,7 @@ def op_bytes(op, L):
     if oc in (L.OP_POOL_FWD, L.OP_POOL_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
         i, o = n * h * w * c, n * h * w * c // 4
-        if oc == L.OP_POOL_FWD:
-            return (i + o) * ab + (o if op.p[2] else 0)        # + argmax bytes when the backward is fused
-        return i * ab + i * 4 + o * 4
+        return (i + o) * ab if oc == L.OP_POOL_FWD else i * ab + i * 4 + o * 4
     if oc in (L.OP_UPADD_FWD, L.OP_UPADD_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
         a, b = n * h * w * c, n * h * w * c // 4
@@ -216,7 +214,9 @@ def op_name(op, L):
         gemm = ''
         if kind == 'bwd':
             gemm = ',1' if (d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA')) else ',0'
-            gemm += ',true' if d.dy_pool_idx else ',false'
+            gemm += ',true' if d.pool_idx else ',false'
+        else:
+            gemm = ',true' if d.pool_out else ',false'      # forward: fused pooling outputs
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"
                 f"{'true' if packed and not big else 'false'}{gemm}>")
     return names.get(op.opcode, f'op{op.opcode}')

@@ -45,12 +45,7 @@ typedef struct YunetBN {
 } YunetBN;
 
 /* Input transform of a fused unit (how it reads its input tensor). */
-enum { YUNET_T_IDENTITY = 0, YUNET_T_BNRELU = 1,
-       /* backward only: x is max_pool2d(relu(bn(.)), 2) of the producer (already transformed, used as it
-        * is); in_bn carries the producer's gamma / beta / bstats.  dx is written with the ReLU mask
-        * (x > 0) and the producer's BN-backward sums are accumulated from x itself:
-        * xhat = (x - beta) / gamma at the window maximum (gamma == 0: that channel's xhat sum is 0). */
-       YUNET_T_POOLED = 2 };
+enum { YUNET_T_IDENTITY = 0, YUNET_T_BNRELU = 1 };
 
 /* Storage type of ACTIVATION tensors (raw conv outputs, pool / upsample-add outputs).  YUNET_BF16 is
  * BASELINE.json configs[2] "bf16 fwd / fp32 grads": activations are kept as bf16 in HBM and the
@@ -87,12 +82,19 @@ typedef struct YunetDP {
     unsigned long long* prof;  /* optional [grid,8] per-workgroup phase cycle counters (or NULL) */
     int32_t x_dtype;           /* YUNET_F32 | YUNET_BF16: storage of x (and of z unless z_dtype says otherwise) */
     int32_t z_dtype;           /* storage of z: equals x_dtype, except the fused heads, whose z is the fp32 [N,P,16] */
-    const uint8_t* dy_pool_idx; /* backward only, or NULL.  Not NULL: the unit's output went through BN+ReLU+max_pool2d(2)
-                                  and nothing else; dy is then the POOLED gradient [N,H/2,W/2,cout] (ReLU mask applied,
-                                  as a YUNET_T_POOLED consumer writes it) and dy_pool_idx [N,H/2,W/2,cout] the window
-                                  position 2*dy+dx of each maximum (yunet_pool_fwd_argmax): the max_pool2d backward
-                                  happens while the tile is staged, no full-size dy tensor exists.  Supported where
-                                  yunet_dp_bwd_pooled_dy_ok() says so. */
+    /* Fused max_pool2d(2) of this unit's BN+ReLU output (both NULL: none).  Where yunet_dp_pool_fusion_ok()
+     * says so and the pool is the output's ONLY consumer:
+     *   forward : pool_out [N,H/2,W/2,cout] (activation storage type) receives, per 2x2 window and channel, the
+     *             RAW z that wins the window after BN+ReLU (the maximum for gamma > 0, the minimum for gamma < 0,
+     *             the first element for gamma == 0) and pool_idx [N,H/2,W/2,cout] its window position 2*dy + dx
+     *             (ties: the smaller position, as F.max_pool2d).  The consumer reads pool_out with
+     *             in_transform = BNRELU and THIS unit's BN (count = N*H*W): relu(bn(.)) is monotone, so that is
+     *             max_pool2d(relu(bn(z))) exactly, and its backward yields the BN-backward sums unchanged.
+     *   backward: pool_idx != NULL: dy is the POOLED gradient [N,H/2,W/2,cout] the consumer wrote as its dx
+     *             (ReLU mask applied); it reaches the recorded window position while the tile is staged -- no
+     *             full-size gradient of z exists. */
+    float* pool_out;
+    uint8_t* pool_idx;
 } YunetDP;
 
 /* ---- conv stack (mmdet/models/utils/yunet_layer.py, backbones/yunet_backbone.py:33-41,
@@ -113,17 +115,14 @@ int yunet_dp_fwd(const YunetDP* d, void* stream);
 int yunet_dp_bwd(const YunetDP* d, void* stream);
 /* rows of wgrad_partials (= persistent grid) yunet_dp_bwd / yunet_stem_bwd use for a shape */
 int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
+/* 1 if yunet_dp_fwd / yunet_dp_bwd accept YunetDP.pool_out / pool_idx for this shape (the unpacked
+ * 16->16 units on maps >= 32x64 and the unpacked 64->64 units; H, W even) */
+int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout);
 int yunet_stem_bwd_blocks(int N, int H, int W);
 
 /* F.max_pool2d(relu(bn(z)), 2)  (yunet_backbone.py:39-40).  out [N,H/2,W/2,C]. */
 int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
                    void* stream);
-/* the same, also recording the window position (2*dy + dx, first maximum in that order, like
- * F.max_pool2d's indices) of every output element: argmax [N,H/2,W/2,C] bytes, or NULL. */
-int yunet_pool_fwd_argmax(const float* z, const YunetBN* bn, float* out, uint8_t* argmax, int N, int H,
-                          int W, int C, void* stream);
-/* 1 if yunet_dp_bwd accepts YunetDP.dy_pool_idx for this shape (the unpacked 16->16 and 64->64 units) */
-int yunet_dp_bwd_pooled_dy_ok(int N, int H, int W, int cin, int cout);
 /* dy_out [N,H/2,W/2,C] -> dz-side grad wrt bn output (mask applied) [N,H,W,C]; accumulates
  * bn->bstats.  accumulate != 0: dx += . */
 int yunet_pool_bwd(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
@@ -280,8 +279,6 @@ int yunet_dp_fwd_bf16(const YunetDP* d, void* stream);
 int yunet_dp_bwd_bf16(const YunetDP* d, void* stream);
 int yunet_pool_fwd_bf16(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
                         void* stream);
-int yunet_pool_fwd_argmax_bf16(const float* z, const YunetBN* bn, float* out, uint8_t* argmax, int N, int H,
-                               int W, int C, void* stream);
 int yunet_pool_bwd_bf16(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
                         int accumulate, int N, int H, int W, int C, void* stream);
 int yunet_upadd_fwd_bf16(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,

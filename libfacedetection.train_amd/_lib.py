@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('YUNET_HIP_LIB') or os.path.join(_HERE, 'libyunet_hip.
 c_f32p = C.c_void_p
 MAX_LEVELS = 5
 
-T_IDENTITY, T_BNRELU, T_POOLED = 0, 1, 2
+T_IDENTITY, T_BNRELU = 0, 1
 F32, BF16 = 0, 1
 BOX_EIOU, BOX_DIOU = 0, 1
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
@@ -36,7 +36,7 @@ class YunetDP(C.Structure):
                 ('dy', C.c_void_p), ('dy_scale', C.c_void_p), ('dx', C.c_void_p),
                 ('wgrad_partials', C.c_void_p), ('wgrad_blocks', C.c_int32),
                 ('prof', C.c_void_p), ('x_dtype', C.c_int32), ('z_dtype', C.c_int32),
-                ('dy_pool_idx', C.c_void_p)]
+                ('pool_out', C.c_void_p), ('pool_idx', C.c_void_p)]
 
 
 class YunetLevels(C.Structure):
@@ -75,9 +75,7 @@ _SIGNATURES = {
     'yunet_stem_bwd_blocks': (C.c_int, [C.c_int] * 3),
     'yunet_pool_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 4 +
                        [C.c_void_p]),
-    'yunet_pool_fwd_argmax': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p] + [C.c_int] * 4 +
-                              [C.c_void_p]),
-    'yunet_dp_bwd_pooled_dy_ok': (C.c_int, [C.c_int] * 5),
+    'yunet_dp_pool_fusion_ok': (C.c_int, [C.c_int] * 5),
     'yunet_pool_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p] +
                        [C.c_int] * 5 + [C.c_void_p]),
     'yunet_upadd_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.POINTER(YunetBN),
@@ -113,8 +111,7 @@ _SIGNATURES = {
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
 }
-for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_fwd_argmax',
-           'yunet_pool_bwd',
+for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
            'yunet_upadd_fwd', 'yunet_upadd_bwd'):
     _SIGNATURES[_n + '_bf16'] = _SIGNATURES[_n]      # same arguments, bf16 activation storage
 

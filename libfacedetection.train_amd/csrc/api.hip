@@ -83,7 +83,6 @@ int yunet_stem_bwd_bf16(const float*, const float*, const float*, const YunetBN*
 int yunet_dp_fwd_bf16(const YunetDP*, void*);
 int yunet_dp_bwd_bf16(const YunetDP*, void*);
 int yunet_pool_fwd_bf16(const float*, const YunetBN*, float*, int, int, int, int, void*);
-int yunet_pool_fwd_argmax_bf16(const float*, const YunetBN*, float*, uint8_t*, int, int, int, int, void*);
 int yunet_pool_bwd_bf16(const float*, const YunetBN*, const float*, float*, int, int, int, int, int, void*);
 int yunet_upadd_fwd_bf16(const float*, const YunetBN*, const float*, const YunetBN*, float*, int, int, int, int, void*);
 int yunet_upadd_bwd_bf16(const float*, const YunetBN*, const float*, const YunetBN*, const float*, float*, int, float*,
@@ -114,8 +113,8 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
                 rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_bwd_bf16(&o.dp, stream) : yunet_dp_bwd(&o.dp, stream);
                 break;
             case YUNET_OP_POOL_FWD:
-                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_fwd_argmax_bf16 : yunet_pool_fwd_argmax)(
-                    (const float*)o.p[0], &o.bn[0], (float*)o.p[1], (uint8_t*)o.p[2], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_fwd_bf16 : yunet_pool_fwd)((const float*)o.p[0], &o.bn[0], (float*)o.p[1], o.i[0], o.i[1],
+                                    o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_POOL_BWD:
                 rc = (o.i[11] == YUNET_BF16 ? yunet_pool_bwd_bf16 : yunet_pool_bwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1],

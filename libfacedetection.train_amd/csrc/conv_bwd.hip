@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int H = d.H, W = d.W;
-    const bool bn_in = d.in_transform != YUNET_T_IDENTITY;      // BNRELU, or POOLED (mask + sums from x itself)
+    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
     const bool bn_out = d.out_has_bn != 0;
     // The input transform is applied branch-free where MFMA operands are read: with the identity
     // coefficients (mean 0, scale 1, beta 0) and a floor of -inf it returns its argument exactly,
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     float4 pdy[G::NDZ];
     act_raw4 pz[G::NDZ], px[G::NX];          // saved activations: storage type of this build (fp32 | bf16)
     unsigned okmask = 0;
-    // POOLDY (YunetDP.dy_pool_idx): the unit's output feeds max_pool2d and nothing else.  A halo slot then
+    // POOLDY (YunetDP.pool_idx): the unit's output feeds max_pool2d and nothing else.  A halo slot then
     // loads the gradient of ITS pooled element and that element's argmax bytes (4 channels = one dword);
     // the stage keeps the gradient where the slot is the window maximum.  posmask: window position
     // 2*(y&1) + (x&1) of every slot, two bits each.
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(d.dy) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : zbase), 0, POOLDY ? pooledbytes : dyrange, 0x00020000);
         const auto r_id = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(d.dy_pool_idx) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0,
+            d.pool_idx + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0,
             POOLDY ? pooledbytes / 4u : 0u, 0x00020000);
         const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
@@ -346,14 +346,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         }
     }
     for (int c = tid; c < CIN; c += BWD_THREADS) {
-        if (d.in_transform == YUNET_T_POOLED) {
-            // x = max_pool2d(relu(bn(z))) is used as it is (mean 0, scale 1, beta 0); ReLU mask x > 0;
-            // xhat at the window maximum from x itself: ((x - 0) - beta) * (1 / gamma)
-            const float gm = d.in_bn.gamma[c];
-            s_ci[c] = 0.f; s_ci[CIN + c] = 1.f; s_ci[2 * CIN + c] = 0.f;
-            s_ci[3 * CIN + c] = gm != 0.0f ? 1.0f / gm : 0.0f;
-            s_ci[4 * CIN + c] = d.in_bn.beta[c];
-        } else if (bn_in) {
+        if (bn_in) {
             const BNCoef k = bn_coef(d.in_bn, CIN, c);
             s_ci[c] = k.mean; s_ci[CIN + c] = k.scale; s_ci[2 * CIN + c] = k.beta;
             s_ci[3 * CIN + c] = k.invstd; s_ci[4 * CIN + c] = k.mean_lo;
@@ -1342,7 +1335,7 @@ static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
 }
 #ifdef YUNET_ACT_BF16
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
-extern "C" int yunet_dp_bwd_pooled_dy_ok(int N, int H, int W, int cin, int cout);
+extern "C" int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout);
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W);
 #else
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
@@ -1353,7 +1346,7 @@ extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
                                   : (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
     return (int)(tiles < DP_BWD_MAX_BLOCKS ? tiles : DP_BWD_MAX_BLOCKS);
 }
-extern "C" int yunet_dp_bwd_pooled_dy_ok(int N, int H, int W, int cin, int cout) {
+extern "C" int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout) {
     if ((H & 1) || (W & 1)) return 0;
     if (cin == 16 && cout == 16) return dp_bwd_big_tile(H, W, cin, cout) ? 1 : 0;
     if (cin == 64 && cout == 64) return dp_use_pack_bwd(N, H, W, cin, cout) ? 0 : 1;
@@ -1371,11 +1364,10 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (!d->wgrad_partials ||
         d->wgrad_blocks != yunet_dp_bwd_blocks(d->N, d->H, d->W, d->cin, d->cout))
         return YUNET_EINVAL;   // the partial buffer must have exactly the rows the grid writes
-    if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU && d->in_transform != YUNET_T_POOLED)
-        return YUNET_EINVAL;
-    if (d->dy_pool_idx) {
+    if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU) return YUNET_EINVAL;
+    if (d->pool_idx) {
         // dy is the pooled gradient + argmax bytes (max_pool2d backward while staging)
-        if (!yunet_dp_bwd_pooled_dy_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
+        if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
         return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
     }

@@ -209,8 +209,14 @@ struct DpGeom {
     static_assert(256 % C4I == 0, "load mapping");
 };
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED>
+// POOL (YunetDP.pool_out): the unit's output goes through BN + ReLU + max_pool2d(2).  BN + ReLU is monotone
+// per channel (rising for gamma > 0, falling for gamma < 0), so the window element that wins AFTER the
+// transform is the raw maximum / minimum: the depthwise phase writes, next to z, the raw winner of every 2x2
+// window [N,H/2,W/2,COUT] and its window position 2*dy + dx (one byte per element).  The consumer reads the
+// pooled tensor with the ordinary BN+ReLU input transform -- no pooling kernel, no second pass over z.
+template <int CIN, int COUT, int TH, int TW, bool PACKED, bool POOL = false>
 __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const PackGeom pk) {
+    static_assert(!(POOL && PACKED) && (!POOL || (TH % 2 == 0 && TW % 2 == 0)), "fused pooling: unpacked, even tiles");
     using G = DpGeom<CIN, COUT, TH, TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* buf = reinterpret_cast<float*>(smem_raw);
@@ -318,6 +324,16 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     double st[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = 0.0;
+    // fused pooling: +1 / -1 / 0 per channel = which raw value wins the window after BN + ReLU
+    // (gamma == 0: every element ties, the first one is taken like F.max_pool2d does)
+    float sg[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (POOL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float gm = d.out_bn.gamma[cq * 4 + i];
+            sg[i] = gm > 0.0f ? 1.0f : (gm < 0.0f ? -1.0f : 0.0f);
+        }
+    }
     __syncthreads();
 
     // identity units run the same straight-line transform: (x - 0) * 1 + 0 floored at -inf
@@ -495,6 +511,13 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
             float ts[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) ts[i] = 0.0f;
+            const unsigned pobytes = (unsigned)((H >> 1) * (W >> 1) * COUT) * ACT_B;
+            const auto r_po = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<act_t*>(d.pool_out) + (POOL ? (size_t)n * (pobytes / ACT_B) : (size_t)0), 0,
+                POOL ? pobytes : 0u, 0x00020000);
+            const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(
+                d.pool_idx + (POOL ? (size_t)n * (pobytes / ACT_B) : (size_t)0), 0, POOL ? pobytes / ACT_B : 0u, 0x00020000);
+            float4 oprev = make_float4(0, 0, 0, 0);
             float4 rowA[3], rowB[3], rowC[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -531,6 +554,41 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
                     ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
                 }
+                if constexpr (POOL) {
+                    if ((r & 1) == 0) {
+                        oprev = o;
+                    } else {
+                        // rows r-1 | r of this column, then the column to the right (lane + C4O); ties go to
+                        // the smaller window position
+                        const float a[4] = {oprev.x, oprev.y, oprev.z, oprev.w}, b[4] = {o.x, o.y, o.z, o.w};
+                        float v[4];
+                        unsigned jv = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool lower = b[i] * sg[i] > a[i] * sg[i];
+                            v[i] = lower ? b[i] : a[i];
+                            jv |= (lower ? 2u : 0u) << (8 * i);
+                        }
+                        float pv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pv[i] = __shfl_down(v[i], G::C4O, 64);
+                        const unsigned pj = __shfl_down(jv, G::C4O, 64) | 0x01010101u;
+                        unsigned jw = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float kl = v[i] * sg[i], kr = pv[i] * sg[i];
+                            const unsigned jl = (jv >> (8 * i)) & 3u, jr = (pj >> (8 * i)) & 3u;
+                            const bool right = kr > kl || (kr == kl && jr < jl);
+                            v[i] = right ? pv[i] : v[i];
+                            jw |= (right ? jr : jl) << (8 * i);
+                        }
+                        if (inside && (dtx & 1) == 0) {
+                            const unsigned eq = (unsigned)(((y >> 1) * (W >> 1) + (x >> 1)) * COUT + cq * 4);
+                            act_bufst4(r_po, eq * ACT_B, make_float4(v[0], v[1], v[2], v[3]));
+                            __builtin_amdgcn_raw_buffer_store_b32(jw, r_pi, eq, 0, 0);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     rowA[j] = rowB[j];
@@ -563,12 +621,12 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     }
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED = false>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false, bool POOL = false>
 int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
     using G = DpGeom<CIN, COUT, TH, TW>;
     static int blocks_per_cu = 0;
     if (!blocks_per_cu) {
-        const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW, PACKED>);
+        const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW, PACKED, POOL>);
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
@@ -585,15 +643,14 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
                              : d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
     const int resident = 256 * blocks_per_cu;
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW, PACKED>), dim3(grid), dim3(256), G::SMEM, stream, *d, pk);
+    hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW, PACKED, POOL>), dim3(grid), dim3(256), G::SMEM, stream, *d, pk);
     return hip_status();
 }
 
 // ------------------------------------------------------------------- pool / upsample-add
 // one thread = one float4 of channels of one OUTPUT pixel
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__ z, YunetBN bn,
-                                                       act_t* __restrict__ out,
-                                                       unsigned* __restrict__ argmax, int N, int H, int W,
+                                                       act_t* __restrict__ out, int N, int H, int W,
                                                        int C) {
     const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
     const long long total = (long long)N * Ho * Wo * C4;
@@ -608,19 +665,18 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__
         const int ox = (int)(pix % Wo);
         pix /= Wo;
         const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
-        float m[4] = {0.f, 0.f, 0.f, 0.f};  // relu output >= 0
-        unsigned am = 0;                     // one byte per channel: window position 2*dy + dx of the first maximum
+        float4 m = make_float4(0, 0, 0, 0);  // relu output >= 0
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
-            const float y[4] = {bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta), bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta),
-                                bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta), bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta)};
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (y[i] > m[i]) { m[i] = y[i]; am = (am & ~(0xffu << (8 * i))) | ((unsigned)j << (8 * i)); }
-        }
-        act_st4(out + e * 4, make_float4(m[0], m[1], m[2], m[3]));
-        if (argmax) argmax[e] = am;
+            for (int dx = 0; dx < 2; ++dx) {
+                const float4 v = act_ld4(z + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c4 * 4);
+                m.x = fmaxf(m.x, bnrelu(v.x, k[0].mean, k[0].scale, k[0].beta));
+                m.y = fmaxf(m.y, bnrelu(v.y, k[1].mean, k[1].scale, k[1].beta));
+                m.z = fmaxf(m.z, bnrelu(v.z, k[2].mean, k[2].scale, k[2].beta));
+                m.w = fmaxf(m.w, bnrelu(v.w, k[3].mean, k[3].scale, k[3].beta));
+            }
+        act_st4(out + e * 4, m);
     }
 }
 
@@ -692,6 +748,15 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     if (d->z_dtype != YUNET_ACT_DTYPE && !(d->cout == 16 && d->z_dtype == YUNET_F32)) return YUNET_EINVAL;
+    if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU) return YUNET_EINVAL;
+    if (d->pool_out) {
+        // also write the raw max_pool2d winners + their window positions (fused pooling)
+        if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_bn.gamma || !d->pool_idx ||   // (out_has_bn may be 0: eval())
+            (reinterpret_cast<uintptr_t>(d->pool_idx) & 3))
+            return YUNET_EINVAL;
+        if (d->cin == 16) return launch_dp_fwd<16, 16, 16, 32, false, true>(d, s);
+        return launch_dp_fwd<64, 64, 8, 16, false, true>(d, s);
+    }
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
     if (d->cin == 16 && d->cout == 16 && d->W >= 64 && d->H >= 32)
@@ -709,19 +774,13 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     return YUNET_EINVAL;
 }
 
-extern "C" int ACT_SUFFIX(yunet_pool_fwd_argmax)(const float* z, const YunetBN* bn, float* out, uint8_t* argmax,
-                                                 int N, int H, int W, int C, void* stream) {
-    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
-    if (reinterpret_cast<uintptr_t>(argmax) & 3) return YUNET_EINVAL;     // written one channel quad (4 bytes) at a time
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out),
-                       reinterpret_cast<unsigned*>(argmax), N, H, W, C);
-    return hip_status();
-}
 extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
                                           int C, void* stream) {
-    return ACT_SUFFIX(yunet_pool_fwd_argmax)(z, bn, out, nullptr, N, H, W, C, stream);
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out), N, H, W, C);
+    return hip_status();
 }
 
 extern "C" int ACT_SUFFIX(yunet_upadd_fwd)(const float* za, const YunetBN* bna, const float* zb,

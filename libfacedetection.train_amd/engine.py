@@ -193,8 +193,8 @@ class _T:
         self.img_stride = img_stride if img_stride is not None else h * w * c
         self.grad = None
         self.grad_written = False
-        self.pooled_into = None     # (pooled tensor, argmax bytes) when max_pool2d is this tensor's only consumer
-        self.pool_of = None         # the tensor this one is the fused max_pool2d of
+        self.bn_count = n * h * w   # elements per channel behind the BN statistics of `bn`
+        self.pooled_into = None     # (pooled tensor, window-position bytes) when max_pool2d is this tensor's only consumer
 
 
 class _BNRef:
@@ -223,6 +223,7 @@ class Plan:
         self.act_flag = L.BF16 if eng.precision == 'bf16' else L.F32
         self.keep = []          # python objects that must outlive the op arrays
         self.producer = {}      # id(tensor) -> (cin, cout) of the ConvDPUnit that wrote it
+        self.fwd_op_of = {}     # id(tensor) -> its OP_DP_FWD record
         self.fwd_a, self.fwd_b, self.bwd = [], [], []
         self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
         self.tensors = {}       # unit name -> (input _T, output _T): introspection / debugging
@@ -505,7 +506,7 @@ class Plan:
         d.x_img_stride = x.img_stride
         d.z_img_stride = z_img_stride if z_img_stride is not None else x.h * x.w * u['cout']
         d.x = x.buf.data_ptr()
-        d.in_bn = self._bn_struct(x.bn, x.n * x.h * x.w) if x.bn is not None else _NULL_BN
+        d.in_bn = self._bn_struct(x.bn, x.bn_count) if x.bn is not None else _NULL_BN
         ptrs = lay.unit_ptrs(fp.data, name)
         d.w_pw, d.b_pw, d.w_dw, d.b_dw = ptrs[0], ptrs[1], ptrs[2], ptrs[3]
         d.z = z
@@ -533,6 +534,8 @@ class Plan:
         op = self._op(L.OP_DP_FWD)
         op.dp = d
         self.fwd_a.append(op)
+        if zt is not None:
+            self.fwd_op_of[id(zt)] = op          # _pool() may attach the fused pooling outputs
         blocks = K.dp_grid(x.n, x.h, x.w, u['cin'], u['cout'])
         width = K.dp_row_width(u['cin'], u['cout'])
         part = torch.empty(blocks, width, device=self.eng.device, dtype=torch.float32)
@@ -546,7 +549,7 @@ class Plan:
                 out, idx = zt.pooled_into
                 assert out.grad is not None, f'{name}: pooled output has no gradient'
                 d2.dy = out.grad.data_ptr()
-                d2.dy_pool_idx = idx.data_ptr()
+                d2.pool_idx = idx.data_ptr()
                 d2.dy_scale = None
             elif zt is not None:
                 assert zt.grad is not None, f'{name}: output has no gradient'
@@ -558,13 +561,6 @@ class Plan:
             gx, acc = self._grad_of(x)
             d2.dx = gx.data_ptr()
             d2.accumulate_dx = acc
-            if x.pool_of is not None:
-                # x = max_pool2d(relu(bn(src))): this unit masks dx with x > 0 and accumulates the BN-backward
-                # sums of src's BatchNorm from x itself (YUNET_T_POOLED); src's backward then reads dx + argmax
-                src = x.pool_of
-                assert acc == 0, 'a fused pool output has one consumer'
-                d2.in_transform = L.T_POOLED
-                d2.in_bn = self._bn_struct(src.bn, src.n * src.h * src.w)
             d2.wgrad_partials, d2.wgrad_blocks = part.data_ptr(), blocks
             op = self._op(L.OP_DP_BWD)
             op.dp = d2
@@ -573,24 +569,27 @@ class Plan:
         self.bwd_nodes.append(bwd)
 
     def _pool(self, x, sole_consumer=False):
+        # Fused pooling: when the pool is the only consumer of x and the producing unit has the
+        # build for it, that unit's forward also writes the raw window winners + their positions, the
+        # pool's consumer reads them through the ordinary BN+ReLU input transform of x's BatchNorm, and the
+        # producer's backward expands the pooled gradient on load: no pooling kernels, no full-size dz.
+        prod = self.producer.get(id(x))
+        if (sole_consumer and prod is not None and not os.environ.get('YUNET_NO_POOL_FUSION') and
+                L.load().yunet_dp_pool_fusion_ok(x.n, x.h, x.w, prod[0], prod[1])):
+            out = self._new_t(x.n, x.h // 2, x.w // 2, x.c, bn_name=x.bn)
+            out.bn_count = x.bn_count
+            idx = torch.empty(x.n, x.h // 2, x.w // 2, x.c, device=self.eng.device, dtype=torch.uint8)
+            self.keep.append(idx)
+            fop = self.fwd_op_of[id(x)]
+            fop.dp.pool_out, fop.dp.pool_idx = out.buf.data_ptr(), idx.data_ptr()
+            x.pooled_into = (out, idx)
+            return out
         out = self._new_t(x.n, x.h // 2, x.w // 2, x.c, bn_name=None)
         cnt = x.n * x.h * x.w
-        # Fused backward: when the pool is the only consumer of x and the producing unit has a
-        # pooled-dy build, no full-size gradient of x exists -- pool_fwd records the argmax bytes, the
-        # pool's consumer writes the masked pooled gradient + the BN sums, the producer expands it on load.
-        prod = self.producer.get(id(x))
-        fuse = bool(sole_consumer and prod is not None and not os.environ.get('YUNET_NO_POOL_FUSION') and
-                    L.load().yunet_dp_bwd_pooled_dy_ok(x.n, x.h, x.w, prod[0], prod[1]))
-        idx = torch.empty(x.n, x.h // 2, x.w // 2, x.c, device=self.eng.device, dtype=torch.uint8) if fuse else None
-        op = self._op(L.OP_POOL_FWD, p=[x.buf.data_ptr(), out.buf.data_ptr(), idx.data_ptr() if fuse else None],
+        op = self._op(L.OP_POOL_FWD, p=[x.buf.data_ptr(), out.buf.data_ptr()],
                       i=[x.n, x.h, x.w, x.c])
         op.bn[0] = self._bn_struct(x.bn, cnt)
         self.fwd_a.append(op)
-        if fuse:
-            self.keep.append(idx)
-            x.pooled_into = (out, idx)
-            out.pool_of = x
-            return out
 
         def bwd():
             gx, acc = self._grad_of(x)

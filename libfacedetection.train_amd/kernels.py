@@ -150,10 +150,13 @@ def _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, x_img_stride=None,
     return d
 
 
-def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_stride=None):
+def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_stride=None, pool=False):
     """ConvDPUnit forward.  x [N,H,W,Cin] raw producer output (in_bn given) or activations, fp32 or
     bf16 storage.  Returns raw z [N,H,W,Cout] in x's storage type (pass z to choose: the fused heads
-    write fp32); accumulates out_bn.stats when out_bn is given."""
+    write fp32); accumulates out_bn.stats when out_bn is given.
+    pool=True (fused max_pool2d of the BN+ReLU output): returns (z, pooled, idx) -- pooled [N,H/2,W/2,Cout]
+    holds the RAW z of every window's winner (feed it to the consumer with in_bn = this unit's BN),
+    idx the uint8 window positions 2*dy + dx."""
     _chk_f32(w_pw, b_pw, w_dw, b_dw)
     _chk_act(x, z)
     n, h, w, _ = x.shape
@@ -161,18 +164,20 @@ def dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn=None, out_bn=None, z=None, z_img_str
     if z is None:
         z = torch.empty(n, h, w, cout, device=x.device, dtype=x.dtype)
     d = _dp_desc(x, w_pw, b_pw, w_dw, b_dw, z, in_bn, out_bn, z_img_stride=z_img_stride)
+    if pool:
+        pooled = torch.empty(n, h // 2, w // 2, cout, device=x.device, dtype=x.dtype)
+        idx = torch.empty(n, h // 2, w // 2, cout, device=x.device, dtype=torch.uint8)
+        d.pool_out, d.pool_idx = pooled.data_ptr(), idx.data_ptr()
     L.check(getattr(L.load(), 'yunet_dp_fwd' + _act(x)[1])(C.byref(d), _stream()), 'yunet_dp_fwd')
-    return z
+    return (z, pooled, idx) if pool else z
 
 
 def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=None,
-           dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True, pooled_input=False,
-           dy_pool_idx=None):
+           dx=None, accumulate_dx=False, z_img_stride=None, need_dx=True, pool_idx=None):
     """ConvDPUnit backward.  x, z: saved activations (fp32 or bf16); dy, dx fp32.
     Returns (dx, d_w_pw, d_b_pw, d_w_dw, d_b_dw).
-    pooled_input: x is max_pool2d(relu(bn(src)), 2) and in_bn the BatchNorm of src (YUNET_T_POOLED:
-    dx gets the ReLU mask, in_bn.bstats the BN-backward sums of src).  dy_pool_idx: dy is the pooled
-    gradient [N,H/2,W/2,cout] and dy_pool_idx the argmax bytes of pool_fwd(..., argmax=True)."""
+    pool_idx (the idx of dp_fwd(..., pool=True)): dy is the POOLED gradient [N,H/2,W/2,cout] -- the dx
+    the pool's consumer wrote -- and reaches the recorded window positions while the tile is staged."""
     _chk_f32(w_pw, b_pw, w_dw, b_dw, dy)
     _chk_act(x)
     n, h, w, cin = x.shape
@@ -184,12 +189,10 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
     d.dy_scale = dy_scale.data_ptr() if dy_scale is not None else None
     d.dx = dx.data_ptr() if dx is not None else None
     d.accumulate_dx = int(accumulate_dx)
-    if pooled_input:
-        d.in_transform = L.T_POOLED
-    if dy_pool_idx is not None:
-        assert dy_pool_idx.dtype == torch.uint8 and tuple(dy_pool_idx.shape) == (n, h // 2, w // 2, cout)
+    if pool_idx is not None:
+        assert pool_idx.dtype == torch.uint8 and tuple(pool_idx.shape) == (n, h // 2, w // 2, cout)
         assert tuple(dy.shape) == (n, h // 2, w // 2, cout)
-        d.dy_pool_idx = dy_pool_idx.data_ptr()
+        d.pool_idx = pool_idx.data_ptr()
     blocks = dp_grid(n, h, w, cin, cout)
     width = dp_row_width(cin, cout)
     part = torch.empty(blocks, width, device=x.device, dtype=torch.float32)
@@ -204,15 +207,13 @@ def dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn=None, out_bn=None, dy_scale=N
             out[o3:])
 
 
-def pool_fwd(z, bn, argmax=False):
-    """max_pool2d(relu(bn(z)), 2); argmax=True also returns the uint8 window positions (2*dy + dx)."""
+def pool_fwd(z, bn):
     n, h, w, c = z.shape
     out = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=z.dtype)
-    idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8) if argmax else None
     bnc = bn.c()
-    L.check(getattr(L.load(), 'yunet_pool_fwd_argmax' + _act(z)[1])(_p(z), C.byref(bnc), _p(out), _p(idx) if argmax else None,
-                                                                    n, h, w, c, _stream()), 'yunet_pool_fwd_argmax')
-    return (out, idx) if argmax else out
+    L.check(getattr(L.load(), 'yunet_pool_fwd' + _act(z)[1])(_p(z), C.byref(bnc), _p(out), n, h, w, c, _stream()),
+            'yunet_pool_fwd')
+    return out
 
 
 def pool_bwd(z, bn, dy_out, dx=None, accumulate=False):

@@ -234,22 +234,26 @@ def test_pool_fwd_bwd(c):
 
 
 @pytest.mark.parametrize('c,n,h,w', [(16, 2, 64, 96), (16, 1, 160, 160), (64, 3, 40, 48), (64, 20, 80, 80)])
-def test_fused_pool_backward(c, n, h, w):
-    """unit P -> BN -> ReLU -> max_pool2d(2) -> unit Q without a full-size gradient of P's output:
-    pool_fwd records the argmax bytes, Q's backward (YUNET_T_POOLED) writes the masked pooled gradient and
-    the BN-backward sums of P's BatchNorm (xhat from the pooled value), P's backward (dy_pool_idx) expands
-    it while staging.  Against fp64 autograd through the same graph.  (20, 80, 80) walks the prefetch path."""
+def test_fused_pooling(c, n, h, w):
+    """unit P -> BN -> ReLU -> max_pool2d(2) -> unit Q without a pooling kernel and without a full-size
+    gradient of P's output: P's forward also writes the raw window winners + their positions (some gammas are
+    negative or zero: minimum / first element), Q reads them through the BN+ReLU input transform of P's
+    BatchNorm, Q's backward writes the masked pooled gradient and the BN-backward sums, P's backward
+    (pool_idx) expands it while staging.  Against fp64 autograd through the same graph.
+    (20, 80, 80) walks the prefetch path of both kernels."""
     k = K()
     g = torch.Generator().manual_seed(c + h)
     x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
     P = [t.double().requires_grad_(True) for t in mk_unit(c, c, g)]
     Q = [t.double().requires_grad_(True) for t in mk_unit(c, c, g)]
     gp, bp = (torch.rand(c, generator=g) + 0.5).double(), (torch.randn(c, generator=g) * .3).double()
+    gp[1], gp[c - 3] = -gp[1], -0.7          # falling BN: the window MINIMUM wins
+    gp[5] = 0.0                              # constant channel: first element, like F.max_pool2d
     gq, bq = (torch.rand(c, generator=g) + 0.5).double(), (torch.randn(c, generator=g) * .3).double()
     zp = F.conv2d(F.conv2d(x, P[0], P[1]), P[2], P[3], padding=1, groups=c)
     zbp, xhat_p = bn_ref(zp, gp, bp)
     zbp.retain_grad()
-    pooled = F.max_pool2d(F.relu(zbp), 2)
+    pooled, ref_idx = F.max_pool2d(F.relu(zbp), 2, return_indices=True)
     pooled.retain_grad()
     zq = F.conv2d(F.conv2d(pooled, Q[0], Q[1]), Q[2], Q[3], padding=1, groups=c)
     zbq, xhat_q = bn_ref(zq, gq, bq)
@@ -263,26 +267,34 @@ def test_fused_pool_backward(c, n, h, w):
     xg = nhwc(x.detach().float()).to(DEV)
     pw = [dev(P[0], c, c), dev(P[1]), dev(P[2], c, 9), dev(P[3])]
     qw = [dev(Q[0], c, c), dev(Q[1]), dev(Q[2], c, 9), dev(Q[3])]
-    # forward on the device (the saved tensors of the backward)
     bn_p = k.BN(torch.zeros(2 * c, dtype=torch.float64, device=DEV), dev(gp), dev(bp), n * h * w,
                 bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
-    zpg = k.dp_fwd(xg, *pw, None, bn_p)
-    pooled_g, idx = k.pool_fwd(zpg, bn_p, argmax=True)
+    zpg, praw, idx = k.dp_fwd(xg, *pw, None, bn_p, pool=True)
     torch.cuda.synchronize()
-    assert rel_err(nchw(pooled_g.cpu()), pooled.detach()) < 2e-5
-    # argmax bytes vs F.max_pool2d's indices (window position 2*dy + dx)
-    _, ref_idx = F.max_pool2d(F.relu(zbp.detach()), 2, return_indices=True)
+    assert rel_err(nchw(zpg.cpu()), zp.detach()) < 2e-5
+    # the raw winners, transformed, are the pooled activations
+    mean, var = zp.detach().mean(dim=(0, 2, 3)), zp.detach().var(dim=(0, 2, 3), unbiased=False)
+    act = F.relu((nchw(praw.cpu()).double() - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+                 * gp.view(1, -1, 1, 1) + bp.view(1, -1, 1, 1))
+    assert rel_err(act, pooled.detach()) < 2e-5
+    # window positions vs F.max_pool2d's indices
     ry, rx = ref_idx // w, ref_idx % w
     ref_pos = ((ry % 2) * 2 + rx % 2).to(torch.uint8)
-    live = pooled.detach() > 1e-4                      # dead windows (all zero after the ReLU) carry no gradient
+    live = pooled.detach() > 1e-4                       # dead windows (all zero after the ReLU) carry no gradient
+    live[:, 5] = True                                   # ... but the constant channel must take position 0 everywhere
     agree = (nchw(idx.cpu()) == ref_pos) | ~live
-    assert float(agree.double().mean()) > 0.9999       # (fp32 vs fp64 near-ties may pick the other element)
-    dq = zbq.grad                                       # grad wrt Q's BN output, ReLU mask applied
-    bn_q = k.BN(stats_of(nhwc(zq.detach().float()).to(DEV)), dev(gq), dev(bq), n * (h // 2) * (w // 2),
-                bstats=torch.cat([dq.sum(dim=(0, 2, 3)), (dq * xhat_q.detach()).sum(dim=(0, 2, 3))]).to(DEV).contiguous())
-    zqg = nhwc(zq.detach().float()).to(DEV)
-    dpool, qdw1, qdb1, qdw2, _ = k.dp_bwd(pooled_g, *qw, zqg, nhwc(dq.float()).to(DEV), bn_p, bn_q, pooled_input=True)
-    dxp, pdw1, pdb1, pdw2, _ = k.dp_bwd(xg, *pw, zpg, dpool, None, bn_p, dy_pool_idx=idx)
+    assert float(agree.double().mean()) > 0.9999        # (fp32 vs fp64 near-ties may pick the other element)
+    assert bool((nchw(idx.cpu())[:, 5] == 0).all())
+    # Q forward through the ordinary BN+ReLU input transform of P's BatchNorm
+    bn_q = k.BN(torch.zeros(2 * c, dtype=torch.float64, device=DEV), dev(gq), dev(bq), n * (h // 2) * (w // 2))
+    zqg = k.dp_fwd(praw, *qw, bn_p, bn_q)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(zqg.cpu()), zq.detach()) < 5e-5
+    # backward
+    dq = zbq.grad                                        # grad wrt Q's BN output, ReLU mask applied
+    bn_q.bstats = torch.cat([dq.sum(dim=(0, 2, 3)), (dq * xhat_q.detach()).sum(dim=(0, 2, 3))]).to(DEV).contiguous()
+    dpool, qdw1, qdb1, qdw2, _ = k.dp_bwd(praw, *qw, zqg, nhwc(dq.float()).to(DEV), bn_p, bn_q)
+    dxp, pdw1, pdb1, pdw2, _ = k.dp_bwd(xg, *pw, zpg, dpool, None, bn_p, pool_idx=idx)
     torch.cuda.synchronize()
     tol = 1e-4
     masked = pooled.grad * (pooled.detach() > 0)
