@@ -123,6 +123,23 @@ def op_bytes(op, L):
     return 0
 
 
+def op_bytes_reference_graph(op, L):
+    """The same model over the REFERENCE's op graph: a unit with fused pooling is charged as the plain unit
+    plus the pooling kernel it replaced (forward: read z + write pooled; backward: read z + pooled gradient,
+    write the full-size gradient) -- SURVEY.md 8d's 66.93 MB / image for YuNet_n 320x320."""
+    b = op_bytes(op, L)
+    if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
+        d = op.dp
+        px = d.N * d.H * d.W
+        zb = 2 if d.z_dtype == L.BF16 else 4
+        if op.opcode == L.OP_DP_FWD and d.pool_out:
+            b = px * (d.cin * (2 if d.x_dtype == L.BF16 else 4) + d.cout * zb) + (px + px // 4) * d.cout * zb
+        elif op.opcode == L.OP_DP_BWD and d.pool_idx:
+            b = (px * (d.cin * (2 if d.x_dtype == L.BF16 else 4) + d.cin * 4 + d.cout * 4) +
+                 px * d.cout * zb + px * d.cout * 4 + (px // 4) * d.cout * 4)
+    return b
+
+
 def op_flops(op, L):
     """Algorithmic matrix FLOPs of one launch: the 1x1 pointwise GEMM of a ConvDPUnit is
     2*cin*cout per pixel forward, and two such GEMMs (weight and input gradient) backward.
@@ -250,12 +267,23 @@ def profile_ops(eng, reps=3):
                 a['launches'] += 1
                 a['ms'] += e0.elapsed_time(e1)
                 a['bytes'] += op_bytes(op, L)
+                a['ref_bytes'] = a.get('ref_bytes', 0) + op_bytes_reference_graph(op, L)
                 a['flops'] += op_flops(op, L)
+                if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):      # the same instance runs on several map sizes
+                    sh = a.setdefault('shapes', {}).setdefault(f'{op.dp.H}x{op.dp.W}', dict(launches=0, ms=0.0, bytes=0))
+                    sh['launches'] += 1
+                    sh['ms'] += e0.elapsed_time(e1)
+                    sh['bytes'] += op_bytes(op, L)
     for a in agg.values():
         a['launches'] //= reps
         a['ms'] /= reps
         a['bytes'] //= reps
+        a['ref_bytes'] //= reps
         a['flops'] //= reps
+        for sh in a.get('shapes', {}).values():
+            sh['launches'] //= reps
+            sh['ms'] /= reps
+            sh['bytes'] //= reps
     return agg
 
 
@@ -510,10 +538,18 @@ def main():
             'mfma': {'achieved': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4)},
             'launches_per_step': top['launches'], 'avg_launch_ms': round(per_launch_ms, 4),
+            # the same kernel instance per feature-map size (the step average above mixes them)
+            'by_shape': {k: {'launches': v['launches'], 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                             'frac': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                         for k, v in top.get('shapes', {}).items()},
             'algorithmic_bytes_per_launch': top['bytes'] // top['launches'],
             'share_of_step': round(top['ms'] / tot, 3),
+            # unit-boundary bytes of THIS plan (the two big pools are folded into their neighbours) ...
             'step_algorithmic_GBs': round(sum(v['bytes'] for v in agg.values()) /
                                           (1e-3 * 1000.0 * dt / a.steps) / 1e9, 1),
+            # ... and of the reference's op graph (66.93 MB / image for YuNet_n 320x320) at this rate
+            'step_reference_graph_GBs': round(sum(v['ref_bytes'] for v in agg.values()) /
+                                              (1e-3 * 1000.0 * dt / a.steps) / 1e9, 1),
         }
         res['kernels'] = {k: {'launches': v['launches'], 'ms': round(v['ms'], 4),
                               'GBs': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0}

@@ -209,12 +209,32 @@ def test_bench_byte_model_matches_survey_figures():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     n = 4
-    plan = E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(n, 320, 320, 3)
     conv = (L.OP_STEM_FWD, L.OP_DP_FWD, L.OP_POOL_FWD, L.OP_UPADD_FWD)
-    fwd = sum(bench.op_bytes(op, L) for op in plan.fwd_a if op.opcode in conv)
-    bwd = sum(bench.op_bytes(op, L) for op in plan.bwd)
-    assert fwd / n / 1e6 == pytest.approx(26.43, rel=0.02)
-    assert bwd / n / 1e6 == pytest.approx(40.51, rel=0.02)
+
+    def per_image(plan):
+        return (sum(bench.op_bytes(op, L) for op in plan.fwd_a if op.opcode in conv) / n / 1e6,
+                sum(bench.op_bytes(op, L) for op in plan.bwd) / n / 1e6)
+    # the reference's op graph (separate pooling kernels, YUNET_NO_POOL_FUSION=1): SURVEY's figures
+    os.environ['YUNET_NO_POOL_FUSION'] = '1'
+    try:
+        plan = E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(n, 320, 320, 3)
+    finally:
+        del os.environ['YUNET_NO_POOL_FUSION']
+    fwd, bwd = per_image(plan)
+    assert fwd == pytest.approx(26.43, rel=0.02)
+    assert bwd == pytest.approx(40.51, rel=0.02)
+    # the default plan folds the two big pools into their producers / consumers: the
+    # boundaries pooled tensor -> pool kernel -> full-size gradient disappear from the byte model
+    plan = E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(n, 320, 320, 3)
+    assert sum(op.opcode == L.OP_POOL_FWD for op in plan.fwd_a) == 2
+    assert sum(op.opcode == L.OP_POOL_BWD for op in plan.bwd) == 2
+    fwd, bwd = per_image(plan)
+    assert fwd == pytest.approx(23.35, rel=0.02)
+    assert bwd == pytest.approx(30.88, rel=0.02)
+    # ... and bench.py's reference-graph model charges the fused units as unit + pooling kernel again
+    ref = sum(bench.op_bytes_reference_graph(op, L) for op in list(plan.fwd_a) + list(plan.bwd) if op.opcode in conv or
+              op.opcode in (L.OP_STEM_BWD, L.OP_DP_BWD, L.OP_POOL_BWD, L.OP_UPADD_BWD)) / n / 1e6
+    assert ref == pytest.approx(26.43 + 40.51, rel=0.02)
     # 135.6 M MAC forward per image, 76.5 % of it in the pointwise GEMMs
     pw_flops = sum(bench.op_flops(op, L) for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
     assert pw_flops / n / 2 / 1e6 == pytest.approx(135.6 * 0.765, rel=0.03)
