@@ -116,7 +116,7 @@ int yunet_dp_bwd(const YunetDP* d, void* stream);
 /* rows of wgrad_partials (= persistent grid) yunet_dp_bwd / yunet_stem_bwd use for a shape */
 int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
 /* 1 if yunet_dp_fwd / yunet_dp_bwd accept YunetDP.pool_out / pool_idx for this shape (the unpacked
- * 16->16 units on maps >= 32x64 and the unpacked 64->64 units; H, W even) */
+ * 16->16 units on maps >= 32x64, the 32->64 units and the unpacked 64->64 units; H, W even) */
 int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout);
 int yunet_stem_bwd_blocks(int N, int H, int W);
 

@@ -1350,6 +1350,7 @@ extern "C" int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout) {
     if ((H & 1) || (W & 1)) return 0;
     if (cin == 16 && cout == 16) return dp_bwd_big_tile(H, W, cin, cout) ? 1 : 0;
     if (cin == 64 && cout == 64) return dp_use_pack_bwd(N, H, W, cin, cout) ? 0 : 1;
+    if (cin == 32 && cout == 64) return 1;       // YuNet_s: the unit in front of its 80x80 -> 40x40 pool
     return 0;
 }
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W) {
@@ -1369,6 +1370,7 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
         // dy is the pooled gradient + argmax bytes (max_pool2d backward while staging)
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
+        if (d->cin == 32) return launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
         return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
     }
 #define DP_CASE(ci, co) \

@@ -755,6 +755,7 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
             (reinterpret_cast<uintptr_t>(d->pool_idx) & 3))
             return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_fwd<16, 16, 16, 32, false, true>(d, s);
+        if (d->cin == 32) return launch_dp_fwd<32, 64, 8, 16, false, true>(d, s);
         return launch_dp_fwd<64, 64, 8, 16, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \

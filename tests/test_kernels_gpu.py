@@ -233,8 +233,9 @@ def test_pool_fwd_bwd(c):
     assert rel_err(bn.bstats, ref_b) < 5e-5
 
 
-@pytest.mark.parametrize('c,n,h,w', [(16, 2, 64, 96), (16, 1, 160, 160), (64, 3, 40, 48), (64, 20, 80, 80)])
-def test_fused_pooling(c, n, h, w):
+@pytest.mark.parametrize('ci,c,n,h,w', [(16, 16, 2, 64, 96), (16, 16, 1, 160, 160), (64, 64, 3, 40, 48),
+                                        (64, 64, 20, 80, 80), (32, 64, 3, 40, 48)])
+def test_fused_pooling(ci, c, n, h, w):
     """unit P -> BN -> ReLU -> max_pool2d(2) -> unit Q without a pooling kernel and without a full-size
     gradient of P's output: P's forward also writes the raw window winners + their positions (some gammas are
     negative or zero: minimum / first element), Q reads them through the BN+ReLU input transform of P's
@@ -242,9 +243,9 @@ def test_fused_pooling(c, n, h, w):
     (pool_idx) expands it while staging.  Against fp64 autograd through the same graph.
     (20, 80, 80) walks the prefetch path of both kernels."""
     k = K()
-    g = torch.Generator().manual_seed(c + h)
-    x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
-    P = [t.double().requires_grad_(True) for t in mk_unit(c, c, g)]
+    g = torch.Generator().manual_seed(c + h + ci)
+    x = (torch.randn(n, ci, h, w, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    P = [t.double().requires_grad_(True) for t in mk_unit(ci, c, g)]
     Q = [t.double().requires_grad_(True) for t in mk_unit(c, c, g)]
     gp, bp = (torch.rand(c, generator=g) + 0.5).double(), (torch.randn(c, generator=g) * .3).double()
     gp[1], gp[c - 3] = -gp[1], -0.7          # falling BN: the window MINIMUM wins
@@ -265,7 +266,7 @@ def test_fused_pooling(c, n, h, w):
         t = t.detach().float().to(DEV)
         return t.view(*shape).contiguous() if shape else t
     xg = nhwc(x.detach().float()).to(DEV)
-    pw = [dev(P[0], c, c), dev(P[1]), dev(P[2], c, 9), dev(P[3])]
+    pw = [dev(P[0], c, ci), dev(P[1]), dev(P[2], c, 9), dev(P[3])]
     qw = [dev(Q[0], c, c), dev(Q[1]), dev(Q[2], c, 9), dev(Q[3])]
     bn_p = k.BN(torch.zeros(2 * c, dtype=torch.float64, device=DEV), dev(gp), dev(bp), n * h * w,
                 bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV))
