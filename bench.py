@@ -213,7 +213,7 @@ def op_name(op, L):
     names = {L.OP_STEM_FWD: 'stem_fwd_kernel', L.OP_STEM_BWD: 'stem_bwd_kernel',
              L.OP_POOL_FWD: 'pool_fwd_kernel', L.OP_POOL_BWD: 'pool_bwd_kernel',
              L.OP_UPADD_FWD: 'upadd_fwd_kernel', L.OP_UPADD_BWD: 'upadd_bwd_kernel',
-             L.OP_ASSIGN: 'assign_kernel', L.OP_LOSS: 'loss_kernel',
+             L.OP_ASSIGN: 'assign_compact+topk+resolve_kernel', L.OP_LOSS: 'loss_kernel',
              L.OP_LOSS_NORM: 'loss_norm_kernel', L.OP_LOSS_FINALIZE: 'loss_finalize_kernel',
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
              L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',

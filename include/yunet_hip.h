@@ -181,16 +181,16 @@ typedef struct YunetLevels {
 /* Fused MlvlPointGenerator priors (core/anchor/point_generator.py:80-175, offset 0) +
  * _bbox_decode (yunet_head.py:376-386) + SimOTAAssigner._assign
  * (core/bbox/assigners/sim_ota_assigner.py:95-257, bbox_overlaps
- * core/bbox/iou_calculators/iou2d_calculator.py:232-253) + PseudoSampler, one image per
- * workgroup.  flat [N,P,16] = cls | dx dy dw dh | obj | 10 kps.
+ * core/bbox/iou_calculators/iou2d_calculator.py:232-253) + PseudoSampler, three launches: compaction
+ * of the valid priors per image, top-k per (image, GT) pair, conflict resolution per image.
+ * flat [N,P,16] = cls | dx dy dw dh | obj | 10 kps.
  * gt_boxes [N,Gmax,4] xyxy, gt_kps [N,Gmax,5,3] (x,y,vis), gt_labels [N,Gmax] or NULL,
  * gt_count [N].  Outputs: gt_inds [N,P] int32 (1-based, 0 = background),
  * labels [N,P] int32 (-1 background) or NULL, max_overlaps [N,P] (-1e5 background),
- * img_stats [N,2] = {num_pos, sum of kps weights}.  scratch: [N,P,8] fp32.
+ * img_stats [N,2] = {num_pos, sum of kps weights}.  scratch: [N,P,12] fp32 (ABI 3; 8 words before).
  * Ties at the k-th cost are broken towards the lowest prior index.
- * Limits (YUNET_EINVAL beyond them): P <= 65535 priors per image (16-bit candidate indices in LDS:
- * a 1760x1760 training crop; the shipped configs train at 320 - 640, P <= 8400) and
- * Gmax*sizeof(GT) + 8*P bytes <= 150 KB of LDS (Gmax = 64: P <= 18.7 k). */
+ * Limits (YUNET_EINVAL beyond them): P <= 65535 priors per image (16-bit candidate indices:
+ * a 1760x1760 training crop; the shipped configs train at 320 - 640, P <= 8400), Gmax <= 4096. */
 int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
                  const int32_t* gt_labels, const int32_t* gt_count, const YunetLevels* lv,
                  int N, int P, int Gmax, float center_radius, int32_t* gt_inds,

@@ -85,37 +85,57 @@ struct __attribute__((aligned(16))) VRec {
     float cls_cost, cx, cy, s;
 };
 
-__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
-    const float* __restrict__ flat, const float* __restrict__ gt_boxes,
-    const float* __restrict__ gt_kps, const int32_t* __restrict__ gt_labels,
-    const int32_t* __restrict__ gt_count, Levels L, int P, int Gmax, float radius,
-    int32_t* __restrict__ gt_inds, int32_t* __restrict__ labels, float* __restrict__ max_overlaps,
-    float* __restrict__ img_stats, VRec* __restrict__ scratch_all,
-    const float* __restrict__ pre_scores, const float* __restrict__ pre_boxes) {
+// Work arrays of the assignment in the caller's scratch ([N,P,12] fp32 words):
+//   rec [N][P] VRec (8 words) | cnt [N][P] int32 | vidx [N][P] u16 | mg [N][P] u16 | V [N] int32
+struct AssignScratch {
+    VRec* rec;
+    int* cnt;
+    uint16_t* vidx;
+    uint16_t* mg;
+    int* V;
+};
+__host__ __device__ inline AssignScratch assign_scratch(float* scratch, int N, int P) {
+    AssignScratch a;
+    const size_t np = (size_t)N * P;
+    a.rec = reinterpret_cast<VRec*>(scratch);
+    a.cnt = reinterpret_cast<int*>(scratch + np * 8);
+    a.vidx = reinterpret_cast<uint16_t*>(scratch + np * 9);
+    a.mg = a.vidx + np;
+    a.V = reinterpret_cast<int*>(scratch + np * 10);
+    return a;
+}
+
+// The assignment runs as three launches.  The middle one -- cost and IoU of every valid prior against one
+// GT, top-10 lists, dynamic k -- is all the arithmetic (V x G x ~200 instructions per image) and used to run
+// inside one workgroup per image, 16 waves taking the image's GTs in turn: the step waited for the image
+// with the most faces while most CUs idled.  As its own launch with one wave per (image, GT) pair the pairs
+// of the whole batch spread over the chip.
+//
+// ---- A: decode, region tests, ordered compaction of the valid priors (one workgroup per image) -----------
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_compact_kernel(
+    const float* __restrict__ flat, const float* __restrict__ gt_boxes, const int32_t* __restrict__ gt_count,
+    Levels L, int P, int Gmax, float radius, int32_t* __restrict__ gt_inds, int32_t* __restrict__ labels,
+    float* __restrict__ max_overlaps, AssignScratch ws, const float* __restrict__ pre_scores,
+    const float* __restrict__ pre_boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: gt[Gmax] | cnt[P] int | vidx[P] u16 | mg[P] u16 | misc
     GT* s_gt = reinterpret_cast<GT*>(smem);
-    int* s_cnt = reinterpret_cast<int*>(s_gt + Gmax);
-    uint16_t* s_vidx = reinterpret_cast<uint16_t*>(s_cnt + P);
-    uint16_t* s_mg = s_vidx + ((P + 7) & ~7);
     __shared__ int s_wave_off[ASSIGN_WAVES + 1];
-    __shared__ int s_V;
-    __shared__ float s_red[ASSIGN_WAVES][2];
 
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = min(gt_count[n], Gmax);
     const float* fl = flat + (size_t)n * P * 16;
-    VRec* scratch = scratch_all + (size_t)n * P;
+    VRec* rec_out = ws.rec + (size_t)n * P;
+    int* cnt = ws.cnt + (size_t)n * P;
+    uint16_t* vidx = ws.vidx + (size_t)n * P;
+    uint16_t* mg = ws.mg + (size_t)n * P;
 
     for (int g = tid; g < G; g += ASSIGN_THREADS) {
         const float* b = gt_boxes + ((size_t)n * Gmax + g) * 4;
         s_gt[g] = GT{b[0], b[1], b[2], b[3]};
     }
-    if (tid == 0) s_V = 0;
     __syncthreads();
 
-    // ---- phase A: decode, region tests, ordered compaction of the valid priors -------------
     int vbase = 0;
     for (int p0 = 0; p0 < P; p0 += ASSIGN_THREADS) {
         const int p = p0 + tid;
@@ -175,103 +195,132 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
         __syncthreads();
         if (valid) {
             const int v = vbase + s_wave_off[wid] + __popcll(bal & ((1ull << lane) - 1ull));
-            s_vidx[v] = (uint16_t)p;
-            s_cnt[v] = 0;
-            s_mg[v] = 0;
-            scratch[v] = rec;
+            vidx[v] = (uint16_t)p;
+            cnt[v] = 0;
+            mg[v] = 0;
+            rec_out[v] = rec;
         }
         vbase += s_wave_off[ASSIGN_WAVES];
         __syncthreads();
     }
-    const int V = vbase;
-    // scratch[] written by this block is read back by other waves of this block
-    __threadfence_block();
-    __syncthreads();
+    if (tid == 0) ws.V[n] = vbase;
+}
 
-    // ---- phase B: one wave per GT: dynamic k from the top-10 IoUs, then the k cheapest -----
-    if (V > 0) {
-        for (int g = wid; g < G; g += ASSIGN_WAVES) {
-            const GT gt = s_gt[g];
-            float ti[TOPK];
-            float tc[TOPK];
-            int tv[TOPK];
+// ---- B: one wave per (image, GT): dynamic k from the top-10 IoUs, then the k cheapest -------------------
+#define TOPK_WAVES 4
+__global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
+    const float* __restrict__ gt_boxes, const int32_t* __restrict__ gt_count, int P, int Gmax, int gblocks,
+    float radius, AssignScratch ws) {
+    const int n = blockIdx.x / gblocks;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = (blockIdx.x - n * gblocks) * TOPK_WAVES + wid;
+    const int G = min(gt_count[n], Gmax);
+    const int V = ws.V[n];
+    if (g >= G || V <= 0) return;                 // wave-uniform
+    const VRec* __restrict__ rec = ws.rec + (size_t)n * P;
+    int* cnt = ws.cnt + (size_t)n * P;
+    uint16_t* mg = ws.mg + (size_t)n * P;
+    const float* b = gt_boxes + ((size_t)n * Gmax + g) * 4;
+    const GT gt{b[0], b[1], b[2], b[3]};
+    float ti[TOPK];
+    float tc[TOPK];
+    int tv[TOPK];
+#pragma unroll
+    for (int i = 0; i < TOPK; ++i) {
+        ti[i] = -1.0f;
+        tc[i] = 3.0e38f;
+        tv[i] = 0x7fffffff;
+    }
+    for (int v = lane; v < V; v += 64) {
+        const VRec r = rec[v];
+        float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
+        const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
+        float c = cost_of(r.cls_cost, iou, both);
+        int cv = v;
+        if (iou > ti[TOPK - 1]) {
 #pragma unroll
             for (int i = 0; i < TOPK; ++i) {
-                ti[i] = -1.0f;
-                tc[i] = 3.0e38f;
-                tv[i] = 0x7fffffff;
+                const bool sw = iou > ti[i];
+                const float t = ti[i];
+                ti[i] = sw ? iou : t;
+                iou = sw ? t : iou;
             }
-            for (int v = lane; v < V; v += 64) {
-                const VRec r = scratch[v];
-                float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
-                const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
-                float c = cost_of(r.cls_cost, iou, both);
-                int cv = v;
-                if (iou > ti[TOPK - 1]) {
+        }
+        if (c < tc[TOPK - 1]) {
 #pragma unroll
-                    for (int i = 0; i < TOPK; ++i) {
-                        const bool sw = iou > ti[i];
-                        const float t = ti[i];
-                        ti[i] = sw ? iou : t;
-                        iou = sw ? t : iou;
-                    }
-                }
-                if (c < tc[TOPK - 1]) {
-#pragma unroll
-                    for (int i = 0; i < TOPK; ++i) {
-                        const bool sw = c < tc[i];  // strict: equal costs keep ascending v
-                        const float t = tc[i];
-                        const int u = tv[i];
-                        tc[i] = sw ? c : t;
-                        tv[i] = sw ? cv : u;
-                        c = sw ? t : c;
-                        cv = sw ? u : cv;
-                    }
-                }
-            }
-            // merge: sum of the wave-wide top-10 IoUs in descending order
-            float sum = 0.0f;
-            const int K = V < TOPK ? V : TOPK;
-            for (int k = 0; k < K; ++k) {
-                const float m = wave_max_f(ti[0]);
-                const unsigned long long who = __ballot(ti[0] == m);
-                const int winner = __ffsll((long long)who) - 1;
-                if (lane == winner) {
-#pragma unroll
-                    for (int i = 0; i < TOPK - 1; ++i) ti[i] = ti[i + 1];
-                    ti[TOPK - 1] = -1.0f;
-                }
-                sum = sum + m;
-            }
-            int dk = (int)sum;  // .int(): truncation toward zero
-            dk = dk < 1 ? 1 : dk;
-            for (int k = 0; k < dk; ++k) {
-                const unsigned long long key = ((unsigned long long)ord(tc[0]) << 32) | (uint32_t)tv[0];
-                const unsigned long long kmin = wave_min_u64(key);
-                if (key == kmin && tv[0] != 0x7fffffff) {
-                    const int v = tv[0];
-                    atomicAdd(&s_cnt[v], 1);
-                    s_mg[v] = (uint16_t)g;
-#pragma unroll
-                    for (int i = 0; i < TOPK - 1; ++i) {
-                        tc[i] = tc[i + 1];
-                        tv[i] = tv[i + 1];
-                    }
-                    tc[TOPK - 1] = 3.0e38f;
-                    tv[TOPK - 1] = 0x7fffffff;
-                }
+            for (int i = 0; i < TOPK; ++i) {
+                const bool sw = c < tc[i];  // strict: equal costs keep ascending v
+                const float t = tc[i];
+                const int u = tv[i];
+                tc[i] = sw ? c : t;
+                tv[i] = sw ? cv : u;
+                c = sw ? t : c;
+                cv = sw ? u : cv;
             }
         }
     }
-    __syncthreads();
+    // merge: sum of the wave-wide top-10 IoUs in descending order
+    float sum = 0.0f;
+    const int K = V < TOPK ? V : TOPK;
+    for (int k = 0; k < K; ++k) {
+        const float m = wave_max_f(ti[0]);
+        const unsigned long long who = __ballot(ti[0] == m);
+        const int winner = __ffsll((long long)who) - 1;
+        if (lane == winner) {
+#pragma unroll
+            for (int i = 0; i < TOPK - 1; ++i) ti[i] = ti[i + 1];
+            ti[TOPK - 1] = -1.0f;
+        }
+        sum = sum + m;
+    }
+    int dk = (int)sum;  // .int(): truncation toward zero
+    dk = dk < 1 ? 1 : dk;
+    for (int k = 0; k < dk; ++k) {
+        const unsigned long long key = ((unsigned long long)ord(tc[0]) << 32) | (uint32_t)tv[0];
+        const unsigned long long kmin = wave_min_u64(key);
+        if (key == kmin && tv[0] != 0x7fffffff) {
+            const int v = tv[0];
+            atomicAdd(&cnt[v], 1);
+            mg[v] = (uint16_t)g;       // read back only where cnt ends at 1: then this is the only writer
+#pragma unroll
+            for (int i = 0; i < TOPK - 1; ++i) {
+                tc[i] = tc[i + 1];
+                tv[i] = tv[i + 1];
+            }
+            tc[TOPK - 1] = 3.0e38f;
+            tv[TOPK - 1] = 0x7fffffff;
+        }
+    }
+}
 
-    // ---- phase C: conflicts -> argmin over ALL gts; outputs; per-image statistics ----------
+// ---- C: conflicts -> argmin over ALL gts; outputs; per-image statistics (one workgroup per image) -------
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve_kernel(
+    const float* __restrict__ gt_boxes, const float* __restrict__ gt_kps, const int32_t* __restrict__ gt_labels,
+    const int32_t* __restrict__ gt_count, int P, int Gmax, float radius, int32_t* __restrict__ gt_inds,
+    int32_t* __restrict__ labels, float* __restrict__ max_overlaps, float* __restrict__ img_stats,
+    AssignScratch ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GT* s_gt = reinterpret_cast<GT*>(smem);
+    __shared__ float s_red[ASSIGN_WAVES][2];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = min(gt_count[n], Gmax);
+    const int V = ws.V[n];
+    const VRec* __restrict__ rec = ws.rec + (size_t)n * P;
+    const int* cnt = ws.cnt + (size_t)n * P;
+    const uint16_t* vidx = ws.vidx + (size_t)n * P;
+    const uint16_t* mg = ws.mg + (size_t)n * P;
+    for (int g = tid; g < G; g += ASSIGN_THREADS) {
+        const float* b = gt_boxes + ((size_t)n * Gmax + g) * 4;
+        s_gt[g] = GT{b[0], b[1], b[2], b[3]};
+    }
+    __syncthreads();
     float npos = 0.0f, wsum = 0.0f;
     for (int v = tid; v < V; v += ASSIGN_THREADS) {
-        const int c = s_cnt[v];
+        const int c = cnt[v];
         if (c == 0) continue;
-        const VRec r = scratch[v];
-        int g = s_mg[v];
+        const VRec r = rec[v];
+        int g = mg[v];
         if (c > 1) {
             float best = 3.0e38f;
             for (int j = 0; j < G; ++j) {
@@ -286,7 +335,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(
             }
         }
         const float iou = iou_of(r.x1, r.y1, r.x2, r.y2, s_gt[g]);
-        const int p = s_vidx[v];
+        const int p = vidx[v];
         gt_inds[(size_t)n * P + p] = g + 1;
         max_overlaps[(size_t)n * P + p] = iou;
         if (labels) labels[(size_t)n * P + p] = gt_labels ? gt_labels[(size_t)n * Gmax + g] : 0;
@@ -561,13 +610,17 @@ extern "C" int yunet_assign_ex(const float* flat, const float* pre_scores, const
         return YUNET_EINVAL;
     Levels L = make_levels(lv);
     if (L.base[YUNET_MAX_LEVELS] != P) return YUNET_EINVAL;
-    size_t lds = (size_t)Gmax * sizeof(GT) + (size_t)P * 4 + 2 * (size_t)((P + 7) & ~7) * 2;
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 150 * 1024) return YUNET_EINVAL;
-    hipLaunchKernelGGL(assign_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, (hipStream_t)stream, flat,
-                       gt_boxes, gt_kps, gt_labels, gt_count, L, P, Gmax, center_radius, gt_inds,
-                       labels, max_overlaps, img_stats, reinterpret_cast<VRec*>(scratch), pre_scores,
-                       pre_boxes);
+    const size_t lds = (size_t)Gmax * sizeof(GT);
+    if (lds > 64 * 1024) return YUNET_EINVAL;
+    const AssignScratch ws = assign_scratch(scratch, N, P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(assign_compact_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, st, flat, gt_boxes, gt_count, L, P,
+                       Gmax, center_radius, gt_inds, labels, max_overlaps, ws, pre_scores, pre_boxes);
+    const int gblocks = (Gmax + TOPK_WAVES - 1) / TOPK_WAVES;
+    hipLaunchKernelGGL(assign_topk_kernel, dim3(N * gblocks), dim3(TOPK_WAVES * 64), 0, st, gt_boxes, gt_count, P, Gmax,
+                       gblocks, center_radius, ws);
+    hipLaunchKernelGGL(assign_resolve_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, st, gt_boxes, gt_kps, gt_labels,
+                       gt_count, P, Gmax, center_radius, gt_inds, labels, max_overlaps, img_stats, ws);
     return -(int)hipGetLastError();
 }
 

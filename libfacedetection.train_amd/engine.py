@@ -294,7 +294,7 @@ class Plan:
         self.gt_inds = torch.empty(n, self.P, device=dev, dtype=torch.int32)
         self.max_overlaps = torch.empty(n, self.P, **f32)
         self.img_stats = torch.empty(n, 2, **f32)
-        self.scratch = torch.empty(n, self.P, 8, **f32)
+        self.scratch = torch.empty(n, self.P, 12, **f32)     # yunet_assign work arrays
         self.norm = torch.zeros(4, **f32)
         self.losses = torch.zeros(8, **f32)        # cls, bbox, obj, kps, total (3 spare)
         lib = L.load()

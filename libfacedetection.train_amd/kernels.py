@@ -320,7 +320,7 @@ def assign(flat, gt_boxes, gt_kps, gt_count, sizes, strides, center_radius=2.5, 
     ovl = torch.empty(n, p, device=dev, dtype=torch.float32)
     labels = torch.empty(n, p, device=dev, dtype=torch.int32) if want_labels else None
     img_stats = torch.empty(n, 2, device=dev, dtype=torch.float32)
-    scratch = torch.empty(n, p, 8, device=dev, dtype=torch.float32)
+    scratch = torch.empty(n, p, 12, device=dev, dtype=torch.float32)
     lv = make_levels(sizes, strides)
     L.check(L.load().yunet_assign_ex(_p(flat), _p(pre_scores), _p(pre_boxes), _p(gt_boxes),
                                      _p(gt_kps), _p(gt_labels), _p(gt_count), C.byref(lv), n, p,
