@@ -78,6 +78,17 @@ struct BoxSrc {
     }
 };
 
+// Order-preserving map of an fp32 score onto an unsigned key (and back): raw float bits are monotone only
+// for non-negative values -- a negative score (yunet_nms accepts any score_thr, default -inf) has the sign
+// bit set and would sort above every positive one, in reversed order.
+__device__ __forceinline__ unsigned score_key(float s) {
+    const unsigned u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 template <typename KeyPtr, typename Src>
 __device__ __forceinline__ void sort_decode_nms(KeyPtr keys, int padn, int K, const Src& src, float iou_thr,
                                                 int max_out, float4* __restrict__ gbox, float4* sbox,
@@ -116,7 +127,7 @@ __device__ __forceinline__ void sort_decode_nms(KeyPtr keys, int padn, int K, co
             const unsigned long long key = keys[i];
             const float4 bi = i < DET_BOX_CAP ? sbox[i] : gbox[i];
             dn[i * 5 + 0] = bi.x; dn[i * 5 + 1] = bi.y; dn[i * 5 + 2] = bi.z; dn[i * 5 + 3] = bi.w;
-            dn[i * 5 + 4] = __uint_as_float((unsigned)(key >> 32));
+            dn[i * 5 + 4] = key_score((unsigned)(key >> 32));
             src.extra((int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)), i, kn, keep_n);
         }
         if (tid == 0) *count_n = nout;
@@ -137,7 +148,7 @@ __device__ __forceinline__ void sort_decode_nms(KeyPtr keys, int padn, int K, co
         if (tid == 0) {
             const unsigned long long key = key_i;
             dn[o * 5 + 0] = bi.x; dn[o * 5 + 1] = bi.y; dn[o * 5 + 2] = bi.z; dn[o * 5 + 3] = bi.w;
-            dn[o * 5 + 4] = __uint_as_float((unsigned)(key >> 32));
+            dn[o * 5 + 4] = key_score((unsigned)(key >> 32));
             src.extra((int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)), o, kn, keep_n);
         }
         kept = o + 1;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(
         const bool ok = FROM_HEAD ? hsrc.score(p, score_thr, sc_) : bsrc.score(p, score_thr, sc_);
         if (ok) {
             const unsigned long long key =
-                ((unsigned long long)__float_as_uint(sc_) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
+                ((unsigned long long)score_key(sc_) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
             const int slot = atomicAdd(&s_k, 1);
             if (small) skeys[slot] = key;
             else gkeys[slot] = key;

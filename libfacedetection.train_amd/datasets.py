@@ -91,9 +91,12 @@ def ann_info(info):
 
 
 def imread_bgr(path):
-    """cv2.imread(path, IMREAD_COLOR) stand-in: uint8 [h, w, 3], BGR."""
-    from PIL import Image
+    """cv2.imread(path, IMREAD_COLOR) stand-in: uint8 [h, w, 3], BGR.  Like cv2 (and mmcv.imread's
+    'color' flag) the EXIF orientation tag is APPLIED, so a rotated JPEG decodes in the frame its
+    annotations were made in."""
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
+        im = ImageOps.exif_transpose(im)
         return np.ascontiguousarray(np.asarray(im.convert('RGB'), dtype=np.uint8)[:, :, ::-1])
 
 
@@ -110,6 +113,10 @@ class RetinaFaceDataset:
         self.NK = NK
         self.cat2label = {c: i for i, c in enumerate(self.CLASSES)}
         self.data_infos = load_labelv2(ann_file, min_size, test_mode)
+        if not test_mode:
+            # CustomDataset._filter_imgs (mmdet/datasets/custom.py:119-122, 176-185): training drops
+            # images whose shorter side is below 32 px
+            self.data_infos = [it for it in self.data_infos if min(it['width'], it['height']) >= 32]
         self.flag = np.array([1 if it['width'] / it['height'] > 1 else 0 for it in self.data_infos],
                              dtype=np.uint8)      # CustomDataset._set_group_flag
 
@@ -137,13 +144,19 @@ class RetinaFaceSource:
     of the epoch (seed, epoch, rank, world -> the DistributedGroupSampler role), decoded with PIL on
     the host, augmented on the GPU by the config's own pipeline (pipelines.DevicePipeline)."""
 
-    def __init__(self, dataset, pipeline, samples_per_gpu=16, rank=0, world=1, seed=0, max_gt=64):
+    def __init__(self, dataset, pipeline, samples_per_gpu=16, rank=0, world=1, seed=0, max_gt=64, workers=4):
         from .pipelines import DevicePipeline
         self.ds, self.bs, self.rank, self.world, self.seed = dataset, samples_per_gpu, rank, world, seed
         self.pipe = DevicePipeline(pipeline, seed=seed + 7919 * rank, gmax=64 if max_gt <= 64 else 128)
         per_rank = len(dataset) // world
         self.iters_per_epoch = max(1, per_rank // samples_per_gpu)
         self._perm_epoch, self._perm = None, None
+        # decode ahead: the samples of iteration it + 1 are decoded by a small thread pool (PIL releases
+        # the GIL while decoding) while the GPU runs iteration it -- the role of the reference's
+        # DataLoader workers (workers_per_gpu, mmdet/datasets/builder.py:87-190)
+        self.workers = max(0, int(workers))
+        self._pool = None
+        self._ahead = {}
 
     def _indices(self, it):
         epoch, k = divmod(it, self.iters_per_epoch)
@@ -155,11 +168,25 @@ class RetinaFaceSource:
         base = self.rank * per_rank + k * self.bs
         return [self._perm[(base + j) % len(self.ds)] for j in range(self.bs)]
 
+    def _decoded(self, it):
+        if self.workers == 0:
+            return [self.ds[i] for i in self._indices(it)]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(self.workers)
+        for k in (it, it + 1):                              # this iteration (if not already queued) and the next
+            if k not in self._ahead:
+                self._ahead[k] = [self._pool.submit(self.ds.__getitem__, i) for i in self._indices(k)]
+        futs = self._ahead.pop(it)
+        for k in [k for k in self._ahead if k < it]:        # a caller that jumps around: drop stale work
+            del self._ahead[k]
+        return [f.result() for f in futs]
+
     def batch(self, it, device=None):
         if device is None:
             raise RuntimeError('RetinaFaceSource augments on the GPU: a device is required')
         from .pipelines import SourceBatch
-        samples = [self.ds[i] for i in self._indices(it)]
+        samples = self._decoded(it)
         src = SourceBatch.from_lists([s['img'] for s in samples], [s['gt_bboxes'] for s in samples],
                                      [s['gt_keypointss'] for s in samples], device)
         return self.pipe(src, it)

@@ -20,6 +20,7 @@ class FusedSGD:
         self._lr_dev = None
         self._lr_val = None
         self._steps = 0
+        self._pending = None       # torch-format momentum buffers waiting for the engine's flat layout
         self.grad_scale = 1.0      # multiplies the gradient inside the update kernel (loss-scale removal)
 
     def _bind(self):
@@ -27,6 +28,8 @@ class FusedSGD:
         if eng is None:
             raise RuntimeError('FusedSGD.step() before the first forward_train: no gradients yet')
         n = eng.params.data.numel()
+        if self._pending is not None:
+            self._layout_pending(eng)
         if self._buf is not None and self._buf.numel() == n and self._buf.device != eng.device:
             # a momentum buffer restored from a checkpoint (map_location='cpu') or left behind by
             # model.to(other device): move it, keep the step count -- do NOT restart the momentum
@@ -40,6 +43,22 @@ class FusedSGD:
             self._lr_dev = torch.zeros(1, device=eng.device)
             self._lr_val = None
         return eng
+
+    def _layout_pending(self, eng):
+        """torch.optim.SGD per-parameter momentum buffers -> the engine's flat layout (parameters are views
+        of eng.params.data, so a parameter's offset is the distance of its storage from the flat base)."""
+        params = list(self.model.parameters())
+        flat = torch.zeros_like(eng.params.data)
+        base = eng.params.data.data_ptr()
+        for i, mb in self._pending:
+            p = params[i]
+            off = (p.data_ptr() - base) // 4
+            if off < 0 or off + p.numel() > flat.numel():
+                raise RuntimeError('FusedSGD: a parameter is not a view of the engine\'s flat buffer')
+            flat[off:off + p.numel()].copy_(mb)
+        self._buf = flat
+        self._pending = None
+        self._lr_dev, self._lr_val = None, None
 
     def zero_grad(self, set_to_none=False):
         """Gradients are overwritten (not accumulated) by the fused backward; nothing to do."""
@@ -57,6 +76,8 @@ class FusedSGD:
         self._steps += 1
 
     def state_dict(self):
+        if self._pending is not None and self.model.engine is not None:
+            self._layout_pending(self.model.engine)
         return dict(param_groups=[{k: v for k, v in self.param_groups[0].items() if k != 'params'}],
                     momentum_buffer=None if self._buf is None else self._buf.clone(),
                     steps=self._steps)
@@ -70,6 +91,7 @@ class FusedSGD:
         groups = sd.get('param_groups') or [{}]
         self.param_groups[0].update({k: v for k, v in groups[0].items() if k != 'params'})
         self._lr_dev, self._lr_val = None, None
+        self._pending = None
         if sd.get('momentum_buffer') is not None:
             self._buf = sd['momentum_buffer'].detach().clone().float().reshape(-1)
             self._steps = int(sd.get('steps', 1))
@@ -85,17 +107,15 @@ class FusedSGD:
                     break
                 bufs.append((p, mb))
             if bufs is not None:
-                eng = self.model.engine
-                if eng is None:
-                    raise RuntimeError('load a torch.optim.SGD state after the model is on its GPU '
-                                       '(the flat layout is defined by the engine)')
-                flat = torch.zeros_like(eng.params.data)
-                base = eng.params.data.data_ptr()
-                for p, mb in bufs:
-                    off = (p.data_ptr() - base) // 4
-                    flat[off:off + p.numel()].copy_(mb.reshape(-1))
-                self._buf = flat
+                # The flat layout is defined by the engine, which a model binds lazily at its first
+                # forward -- EpochBasedRunner.resume() (train_detector with resume_from / auto_resume)
+                # loads the optimizer BEFORE any forward.  Keep the per-parameter buffers and lay them out
+                # in _bind(), once the engine exists.
+                self._pending = [(i, mb.detach().clone().float().reshape(-1)) for i, (_, mb) in enumerate(bufs)]
+                self._buf = None
                 self._steps = 1
+                if self.model.engine is not None:
+                    self._layout_pending(self.model.engine)
         else:
             warnings.warn('checkpoint carries no SGD momentum: it restarts from zero')
             self._buf = None

@@ -203,14 +203,21 @@ class Fp16OptimizerHook(OptimizerHook):
         (runner.outputs['loss'] * self.scale).backward()
         target = runner.model.module if hasattr(runner.model, 'module') else runner.model
         grad = target.engine.params.grad
-        if self.dynamic and not bool(torch.isfinite(grad).all()):
-            self.scale = max(self.scale / 2.0, 1.0)
-            self._good = 0
+        # mmcv's GradScaler-based hook skips a step with non-finite gradients for static scales too
+        # (only a dynamic scale is then halved)
+        if not bool(torch.isfinite(grad).all()):
+            if self.dynamic:
+                self.scale = max(self.scale / 2.0, 1.0)
+                self._good = 0
             return                                             # skip the step, like LossScaler
-        if hasattr(opt, 'grad_scale'):
+        if hasattr(opt, 'grad_scale') and self.grad_clip is None:
             opt.grad_scale = 1.0 / self.scale                  # FusedSGD: folded into the update kernel
         else:
+            # clipping measures the norm of the UNSCALED gradient (max_norm must not shrink by the loss
+            # scale): remove the scale in place first
             grad.mul_(1.0 / self.scale)
+            if hasattr(opt, 'grad_scale'):
+                opt.grad_scale = 1.0
         if self.grad_clip is not None:
             params = [p for p in runner.model.parameters() if p.requires_grad and p.grad is not None]
             torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)

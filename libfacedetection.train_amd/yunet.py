@@ -94,6 +94,7 @@ class _EngineStep(torch.autograd.Function):
         """-> loss_cls, loss_bbox, loss_obj, loss_kps and their total (written by the finalize
         kernel): train_step backpropagates the total directly, no tensor arithmetic in between."""
         ctx.model = model
+        ctx.set_materialize_grads(False)      # undefined output grads stay None: backward()'s fast path below
         out = losses.detach().clone()
         return out[0], out[1], out[2], out[3], out[4]
 

@@ -40,11 +40,23 @@ def image_near_tie(flat_n, gt_boxes_n, sizes, strides=(8, 16, 32), rel=4e-7):
                 return True
     K = min(10, d['ious'].shape[0])
     s = torch.sort(d['ious'], dim=0, descending=True).values[:K].sum(0)
-    if float((s - s.round()).abs().min()) < 1e-5:
+    frac = (s - s.round()).abs()
+    frac[s == 0] = 1.0        # no overlapping candidate at all: dynamic_k = max(int(0), 1) is not a rounding question
+    if float(frac.min()) < 1e-5:
         return True
-    two = torch.sort(d['cost'], dim=1).values
-    if two.shape[1] > 1 and float(((two[:, 1] - two[:, 0]) / two[:, 0].abs()).min()) <= rel:
-        return True
+    # conflict resolution: only priors matched to more than one GT take the argmin over their costs
+    cost_m = d['cost']
+    if cost_m.shape[1] > 1:
+        order = torch.argsort(cost_m, dim=0, stable=True)
+        matching = torch.zeros_like(cost_m, dtype=torch.bool)
+        for g in range(cost_m.shape[1]):
+            matching[order[:int(d['dynamic_ks'][g]), g], g] = True
+        multi = matching.sum(1) > 1
+        if bool(multi.any()):
+            two = torch.sort(torch.where(matching[multi], cost_m[multi], torch.full_like(cost_m[multi], float('inf'))),
+                             dim=1).values
+            if float(((two[:, 1] - two[:, 0]) / two[:, 0].abs()).min()) <= rel:
+                return True
     return False
 
 

@@ -117,3 +117,46 @@ def test_dataset_decodes_to_device_pipeline_sources(tmp_path):
     assert s['img'].dtype == np.uint8 and s['img'].shape == (48, 64, 3)
     assert np.array_equal(s['img'][:, :, ::-1], rgb)           # BGR, like cv2.imread
     assert s['gt_bboxes'].shape == (1, 4) and s['gt_keypointss'].shape == (1, 5, 3)
+
+
+def test_dataset_min_side_filter_exif_and_decode_ahead(tmp_path):
+    """CustomDataset._filter_imgs (training drops images with a side below 32 px, custom.py:176-185);
+    the EXIF orientation is applied like cv2.imread; RetinaFaceSource's decode-ahead pool returns the
+    same samples, in the same order, as the synchronous path."""
+    from PIL import Image
+    import yunet_amd
+    import yunet_amd.datasets as DS
+    rng = np.random.default_rng(1)
+    os.makedirs(tmp_path / 'img')
+    txt = ''
+    for i in range(6):
+        rgb = rng.integers(0, 256, (40 + i, 50, 3), dtype=np.uint8)
+        Image.fromarray(rgb).save(tmp_path / 'img' / f'{i}.png')
+        txt += f'# {i}.png 50 {40 + i}\n4 5 30 36 ' + '10 10 1.0 ' * 5 + '0.9\n'
+    txt += '# tiny.png 31 200\n1 2 20 30 ' + '10 10 1.0 ' * 5 + '0.9\n'
+    (tmp_path / 'l.txt').write_text(txt)
+    cfg = dict(type='RetinaFaceDataset', ann_file=str(tmp_path / 'l.txt'), img_prefix=str(tmp_path / 'img'), pipeline=[])
+    ds = yunet_amd.build_dataset(cfg)
+    assert len(ds) == 6 and all(it['filename'] != 'tiny.png' for it in ds.data_infos)
+    assert len(yunet_amd.build_dataset(dict(cfg, test_mode=True))) == 7          # test mode keeps every image
+    # EXIF orientation 6 (rotate 90 degrees clockwise to display): decoded upright, like cv2.imread
+    rgb = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    im = Image.fromarray(rgb)
+    ex = im.getexif()
+    ex[0x0112] = 6
+    im.save(tmp_path / 'rot.jpg', exif=ex, quality=100, subsampling=0)
+    dec = DS.imread_bgr(str(tmp_path / 'rot.jpg'))
+    assert dec.shape == (30, 20, 3)
+    plain = np.asarray(Image.open(tmp_path / 'rot.jpg').convert('RGB'))          # un-rotated decode of the same file
+    assert np.array_equal(dec[:, :, ::-1], np.rot90(plain, k=-1))
+    # decode-ahead == synchronous
+    a = DS.RetinaFaceSource.__new__(DS.RetinaFaceSource)
+    b = DS.RetinaFaceSource.__new__(DS.RetinaFaceSource)
+    for o, w in ((a, 0), (b, 3)):
+        o.ds, o.bs, o.rank, o.world, o.seed = ds, 2, 0, 1, 5
+        o.iters_per_epoch, o._perm_epoch, o._perm = 3, None, None
+        o.workers, o._pool, o._ahead = w, None, {}
+    for it in (0, 1, 2, 3, 4, 7):                                                 # crosses an epoch, then jumps
+        sa, sb = a._decoded(it), b._decoded(it)
+        assert [s['filename'] for s in sa] == [s['filename'] for s in sb]
+        assert all(np.array_equal(x['img'], y['img']) for x, y in zip(sa, sb))

@@ -216,6 +216,15 @@ def test_nms_kernel_vs_oracle_and_counts():
     # iou_thr >= 1: nothing suppressed, everything out in score order
     dets, keep, cnt = k.nms(boxes[:1].to(DEV), scores[:1].to(DEV), 2.0)
     assert int(cnt[0]) == K and torch.equal(keep[0].cpu().long(), torch.sort(scores[0], descending=True).indices)
+    # signed scores (raw logits; score_thr defaults to -inf): the sort key is order-preserving over the whole
+    # fp32 range -- raw float bits would put every negative score first, in reversed order
+    signed = (scores[:1] - 0.5) * 8.0
+    signed[0, 0], signed[0, 1] = float('-inf'), -0.0
+    dets, keep, cnt = k.nms(boxes[:1].to(DEV), signed.to(DEV), 0.45)
+    ref = D.nms_greedy(boxes[0], signed[0], 0.45)
+    m = int(cnt[0])
+    assert m == len(ref) and torch.equal(keep[0, :m].cpu().long(), ref)
+    assert torch.equal(dets[0, :m, 4].cpu(), signed[0, ref])
 
 
 def test_aug_test_single_view_twice_equals_simple_test():

@@ -11,6 +11,8 @@ Properties used:
   * a second run of the same step from the same state reproduces the integer outputs exactly and
     the losses to 1e-6 relative (fp64 atomics only change the summation order of BN sums).
 """
+import os
+
 import pytest
 import torch
 
@@ -132,10 +134,15 @@ def _avail_gb():
         return 1e9
 
 
-@pytest.mark.parametrize('kind,h,n,seed', CONFIGS)
-def test_full_step_vs_oracle(kind, h, n, seed):
+TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yunet_n_synth_trained.pth')
+
+
+@pytest.mark.parametrize('kind,h,n,seed,weights', [c + ('init',) for c in CONFIGS] + [('n', 320, 256, 14, 'trained')])
+def test_full_step_vs_oracle(kind, h, n, seed, weights):
     """The HEADLINE configurations against the CPU oracle at the full batch: one oracle training
-    step on the host (seconds) vs one step of the HIP path.
+    step on the host (seconds) vs one step of the HIP path.  weights = 'trained' is bench.py's own
+    configuration: the trained-checkpoint-like fixture on structured synthetic faces (SimOTA with
+    dynamic_k 7-9 and real conflicts; random initialisation has k = 1 for 90 % of the GTs).
 
     Bars:
       * conv stack: flat [N,P,16] within 5e-4 of the oracle's (max-norm, 20 fp32 layers);
@@ -146,7 +153,8 @@ def test_full_step_vs_oracle(kind, h, n, seed):
         candidate of a few GTs out of ~3000 (costs behind the +1e5 penalty are quantised to 2^-7);
         at most 2 % of the images may differ and the losses then agree to 1e-3 (1e-4 if none do);
       * every parameter gradient: error against an fp64 evaluation of the same conv stack (fed the
-        GPU's own d loss/d flat) at most 3x the oracle's own fp32 error against fp64 + 0.2 %;
+        GPU's own d loss/d flat) at most 3x the oracle's own fp32 error against fp64 + 0.1 %
+        (round 2: 0.2 %, worst measured ratio 0.53);
       * BatchNorm running statistics after the step.
     """
     import yunet_amd
@@ -154,10 +162,14 @@ def test_full_step_vs_oracle(kind, h, n, seed):
     cfg = yunet_amd.Config.fromfile(f'configs/yunet_{kind}.py')
     model = yunet_amd.build_detector(cfg.model)
     arch = O.yunet_arch(kind)
-    sd = O.init_state(arch, seed=seed)
+    if weights == 'trained':
+        sd = {k: v.float() if v.is_floating_point() else v
+              for k, v in torch.load(TRAINED, map_location='cpu', weights_only=False)['state_dict'].items()}
+    else:
+        sd = O.init_state(arch, seed=seed)
     model.load_state_dict(sd, strict=True)
     model.to(DEV).train()
-    b = S.make_batch(n, h, h, seed)
+    b = S.make_batch(n, h, h, seed, structured=weights == 'trained')
     sizes = C.featmap_sizes(h, h)
 
     # ---- HIP path
@@ -211,6 +223,9 @@ def test_full_step_vs_oracle(kind, h, n, seed):
     for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
         assert abs(lg[k] - lo[k]) <= tol_e2e * abs(lo[k]) + 1e-6, (k, lg[k], lo[k], len(diff))
     assert int((gi_g > 0).sum()) > n        # a real assignment, not an empty one
+    if weights == 'trained':
+        npos_per_gt = float((gi_g > 0).sum()) / sum(int(t.shape[0]) for t in b['gt_bboxes'])
+        assert npos_per_gt > 3.0, f'trained fixture: {npos_per_gt:.2f} positives per GT -- dynamic_k > 1 is not exercised'
 
     # (4) parameter gradients against fp64 (two backward passes through one fp64 forward)
     need_gb = 0.1 * n * (h / 320.0) ** 2 * 1.3
@@ -232,10 +247,10 @@ def test_full_step_vs_oracle(kind, h, n, seed):
         for k, a, o in zip(keys, g64_g, g64_o):
             err_hip = float((grads_g[k] - a).abs().max())
             err_ref = float((grads_o[k] - o).abs().max())
-            tol = 3 * max(err_ref, 1e-5 * scale) + 2e-3 * float(a.abs().max())
+            tol = 3 * max(err_ref, 1e-5 * scale) + 1e-3 * float(a.abs().max())
             worst = max(worst, (err_hip / tol, k))
             assert err_hip <= tol, (k, err_hip, err_ref, float(a.abs().max()), scale)
-        print(f'[full step {kind}-{h}-{n}] worst gradient error / tolerance: {worst[0]:.3f} at {worst[1]}; '
+        print(f'[full step {kind}-{h}-{n}-{weights}] worst gradient error / tolerance: {worst[0]:.3f} at {worst[1]}; '
               f'{len(diff)} images differ end to end')
     else:
         # not enough host memory for the fp64 graph: compare with the oracle's fp32 gradients

@@ -297,7 +297,7 @@ def test_fused_pooling(ci, c, n, h, w):
     dpool, qdw1, qdb1, qdw2, _ = k.dp_bwd(praw, *qw, zqg, nhwc(dq.float()).to(DEV), bn_p, bn_q)
     dxp, pdw1, pdb1, pdw2, _ = k.dp_bwd(xg, *pw, zpg, dpool, None, bn_p, pool_idx=idx)
     torch.cuda.synchronize()
-    tol = 1e-4
+    tol = 5e-5                    # the bar of the plain units (test_dp_bwd); 1e-4 until round 3
     masked = pooled.grad * (pooled.detach() > 0)
     assert rel_err(nchw(dpool.cpu()), masked) < tol
     ref_b = torch.cat([zbp.grad.sum(dim=(0, 2, 3)), (zbp.grad * xhat_p.detach()).sum(dim=(0, 2, 3))])
@@ -305,7 +305,7 @@ def test_fused_pooling(ci, c, n, h, w):
     for name, got, want in (('q.dw1', qdw1, Q[0].grad), ('q.db1', qdb1, Q[1].grad), ('q.dw2', qdw2, Q[2].grad),
                             ('p.dx', nchw(dxp.cpu()), x.grad), ('p.dw1', pdw1, P[0].grad), ('p.db1', pdb1, P[1].grad),
                             ('p.dw2', pdw2, P[2].grad)):
-        assert rel_err(got, want) < tol, name
+        assert rel_err(got, want) < tol, (name, float(rel_err(got, want)))
 
 
 def test_upadd_fwd_bwd():
