@@ -422,9 +422,20 @@ __device__ __forceinline__ D4 operator/(D4 a, D4 b) {
     for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
     return r;
 }
-__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return (a.v <= b.v) ? a : b; }
-__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return (a.v >= b.v) ? a : b; }
-__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v > 0.0f ? a : mk(0.0f); }
+// torch.min / torch.max of two tensors split the gradient EVENLY between equal arguments
+// (minimum / maximum backward: grad * (a < b) + grad / 2 * (a == b)); a predicted edge that coincides
+// with its GT edge to the last bit does occur (one prior in ~3000 positives of a crowded 640 x 640 batch,
+// tests/test_loss_step_gpu.py::test_loss_step_crowded_images_vs_oracle).  clamp(min=0) passes the
+// gradient at the boundary (grad * (x >= 0)).
+__device__ __forceinline__ D4 dtie(D4 a, D4 b) {
+    D4 r; r.v = a.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = 0.5f * a.d[i] + 0.5f * b.d[i];
+    return r;
+}
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v == b.v ? dtie(a, b) : (a.v < b.v) ? a : b; }
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v == b.v ? dtie(a, b) : (a.v > b.v) ? a : b; }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v >= 0.0f ? a : mk(0.0f); }
 __device__ __forceinline__ D4 dscale(D4 a, float k) {
     D4 r; r.v = a.v * k;
 #pragma unroll

@@ -226,9 +226,11 @@ def test_bf16_step_on_trained_fixture_bs256():
     test_fullsize_gpu.py::test_full_step_vs_oracle[...-trained]).  The random-init cases above are the
     near-degenerate regime (k = 1, IoU ~ 0: any rounding reorders the candidates); a trained net separates
     its candidates, so the bars here are tighter and STATED:
-      assignment: >= 93 % of the positives of either run are assigned identically; num_pos within 2 %;
-      every loss within 1.5 % of the fp32 value;
-      flat-gradient cosine >= 0.99, and per-layer: every parameter tensor's gradient cosine >= 0.95."""
+      assignment: >= 97 % of the positives of either run are assigned identically (measured 98.8 %);
+      num_pos within 0.5 % (15359 vs 15360); every loss within 1 % of the fp32 value (measured <= 0.34 %);
+      flat-gradient cosine >= 0.999 (measured 0.99966), and per layer: every parameter tensor with at least
+      64 elements has gradient cosine >= 0.98 (1-element tensors -- the cls / obj head biases -- have cosine
+      +-1 by construction and a near-zero value; they are covered by the flat cosine)."""
     import os
     import yunet_amd.synthetic as S
     fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yunet_n_synth_trained.pth')
@@ -241,7 +243,7 @@ def test_bf16_step_on_trained_fixture_bs256():
         sum(losses.values()).backward()
         torch.cuda.synchronize()
         plan = m.engine.plan
-        out[prec] = dict(l={k: float(v) for k, v in losses.items()}, gi=plan.gt_inds.cpu().clone(),
+        out[prec] = dict(l={k: float(v.detach()) for k, v in losses.items()}, gi=plan.gt_inds.cpu().clone(),
                          g=m.engine.params.grad.detach().cpu().clone(),
                          pg={k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()})
         del m
@@ -251,14 +253,15 @@ def test_bf16_step_on_trained_fixture_bs256():
     na, nc = int((a['gi'] > 0).sum()), int((c['gi'] > 0).sum())
     rel = {k: abs(c['l'][k] - a['l'][k]) / abs(a['l'][k]) for k in a['l']}
     cos = float((a['g'] * c['g']).sum() / (a['g'].norm() * c['g'].norm()))
-    layer = {k: float((a['pg'][k] * c['pg'][k]).sum() / (a['pg'][k].norm() * c['pg'][k].norm() + 1e-30)) for k in a['pg']}
+    layer = {k: float((a['pg'][k] * c['pg'][k]).sum() / (a['pg'][k].norm() * c['pg'][k].norm() + 1e-30))
+             for k in a['pg'] if a['pg'][k].numel() >= 64}
     worst = min(layer.items(), key=lambda kv: kv[1])
     print(f'[bf16 trained bs256] agreement {agree:.4f}, num_pos {na} vs {nc}, loss rel err '
           f'{ {k: round(v, 5) for k, v in rel.items()} }, grad cosine {cos:.5f}, worst layer {worst[0]} {worst[1]:.4f}')
     assert na > 5 * 256, 'trained fixture: dynamic_k > 1 is not exercised'
-    assert agree >= 0.93, agree
-    assert abs(na - nc) <= 0.02 * na, (na, nc)
+    assert agree >= 0.97, agree
+    assert abs(na - nc) <= 0.005 * na, (na, nc)
     for k, v in rel.items():
-        assert v <= 1.5e-2, (k, v)
-    assert cos >= 0.99, cos
-    assert worst[1] >= 0.95, worst
+        assert v <= 1e-2, (k, v)
+    assert cos >= 0.999, cos
+    assert worst[1] >= 0.98, worst
