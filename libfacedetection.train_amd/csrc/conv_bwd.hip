@@ -43,6 +43,16 @@ namespace {
 #else
 #define DP_BWD_STAMP(k)
 #endif
+#ifdef DP_BWD_PROF
+#define DP_BWD64_STAMP(k)                                                      \
+    if (prof_on && threadIdx.x == 0) {                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();          \
+        s_prof[k] += now_ - s_prof[7];                                         \
+        s_prof[7] = now_;                                                      \
+    }
+#else
+#define DP_BWD64_STAMP(k)
+#endif
 
 // GEMM = 0: the three pointwise GEMMs on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32).
 // GEMM = 1: split-bf16 -- every fp32 operand x is split on the fly into hi = bf16(x) and
@@ -957,6 +967,643 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     return hip_status();
 }
 
+// ================================================================================================
+// dp_bwd64: the 64 -> 64 ConvDPUnit backward (split-bf16 matrix path), round 3.
+//
+// Same arithmetic as dp_bwd_kernel<64,64,8,16,PACKED,1,POOLDY> above, re-laid for the two units the round-2
+// profile showed busy (VALU 44 %, LDS 38 %, matrix cores 9 %, seven barriers per tile):
+//   * every operand is split into bf16 hi / lo ONCE, where it is produced (a = T(x) in the stage, dp at the end
+//     of the depthwise phase) and lives in LDS as two XOR-swizzled bf16 planes [pixel][channel]; the three GEMMs
+//     read ready-made matrix operands (the old kernel re-split `a` in two GEMMs and `dp` in two);
+//   * the p and da GEMMs are split over OUTPUT channels: a wave owns one 16-channel tile and 4 of the 8 pixel
+//     tiles, and keeps its W1 / W1^T fragments (hi + lo, 32 registers) for the whole launch -- no weight planes in
+//     LDS (37 KB), no weight reads per tile (the old kernel re-read all of W1 from LDS for 16 pixels);
+//   * dW1 (K = pixels) takes its operands from the same row-major planes with the gfx950 transposing LDS read
+//     (ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block and each lane receives one
+//     channel's 4 pixels) -- no second, transposed copy and no in-register transposition;
+//   * the ReLU mask + the producer's BN-backward sums run on the da accumulators in registers (a lane's channel
+//     is fixed for the launch: fp64 partials per lane, reduced once at the end -- no LDS atomics);
+//   * five barriers per tile.
+// LDS: dz halo 45 KB | raw x 32 KB | p / dx staging 32 KB | a planes 32 KB | small tables; the dp planes alias the
+// dz halo (dead after the depthwise phase).
+namespace bwd64 {
+constexpr int C = 64, C4 = 16, TH = 8, TW = 16, HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_, IP = TH * TW;
+constexpr int NDZ = (HP * C4 + BWD_THREADS - 1) / BWD_THREADS;     // 6 (dy, z) float4 pairs per thread
+constexpr int NX = (IP * C4) / BWD_THREADS;                        // 4 x float4 per thread
+constexpr int PSTEP = BWD_THREADS / C4;                            // 32 halo pixels between a thread's slots
+constexpr int PLANE = IP * C * 2;                                  // one bf16 plane: 16 KB
+constexpr int OFF_DZ = 0;                                          // float [HP][64]; later dp planes hi | lo
+constexpr int OFF_X = OFF_DZ + HP * C * 4;                         // float [IP][64] raw x
+constexpr int OFF_P = OFF_X + IP * C * 4;                          // float [IP][64] p, later the masked dx
+constexpr int OFF_A = OFF_P + IP * C * 4;                          // bf16 planes hi | lo of a = T(x)
+constexpr int WORKB = OFF_A + 2 * PLANE;
+constexpr int PAR_F = 9 * C + 7 * C + 5 * C;                       // w2 | out-bn | in-bn (floats)
+#ifdef DP_BWD_PROF
+constexpr int SMEM = WORKB + PAR_F * 4 + 2 * 2 * C * 8 + C * 4 + IP + 64;
+#else
+constexpr int SMEM = WORKB + PAR_F * 4 + 2 * 2 * C * 8 + C * 4 + IP;   // + fp64 sums of the two pixel halves + bias + validity bytes
+#endif
+constexpr int WROW = C * C + C + C * 9 + C;
+constexpr int KSPLIT = 2;                                          // dW1: waves 0-3 pixels 0-63, waves 4-7 pixels 64-127
+static_assert(2 * PLANE <= HP * C * 4, "dp planes alias the dz halo");
+static_assert((size_t)KSPLIT * C * C * 4 + (size_t)BWD_THREADS * 24 * 4 <= (size_t)WORKB, "flush area");
+// byte offset of channels 8*chunk .. 8*chunk+7 of pixel `pix` inside a plane (16-byte chunks, XOR-swizzled so
+// that both the row-wise 16-byte operand reads and the transposing reads are bank-conflict free)
+__device__ __forceinline__ int plane_off(int pix, int chunk) { return pix * (C * 2) + ((chunk ^ (pix & 7)) << 4); }
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// [4 pixels][16 channels] block, transposed: this lane's channel, 4 consecutive pixels (see tools/ubench/tr_probe.hip)
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(
+            (__attribute__((address_space(3))) unsigned char*)p));
+    return __builtin_bit_cast(u32x2, v);
+}
+__device__ __forceinline__ f32x4 mfma3r(const u32x4 ah, const u32x4 al, const u32x4 bh, const u32x4 bl, f32x4 c) {
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah), xl = __builtin_bit_cast(bf16x8, al);
+    const bf16x8 yh = __builtin_bit_cast(bf16x8, bh), yl = __builtin_bit_cast(bf16x8, bl);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, yh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, c, 0, 0, 0);
+    return c;
+}
+}  // namespace bwd64
+
+template <bool PACKED, bool POOLDY>
+__global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
+    using namespace bwd64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* s_dz = reinterpret_cast<float*>(smem_raw + OFF_DZ);
+    float* s_x = reinterpret_cast<float*>(smem_raw + OFF_X);
+    float* s_p = reinterpret_cast<float*>(smem_raw + OFF_P);
+    unsigned char* s_a = smem_raw + OFF_A;                 // planes of a: hi at 0, lo at PLANE
+    unsigned char* s_d = smem_raw + OFF_DZ;                // planes of dp (alias the dz halo)
+    float* s_w2 = reinterpret_cast<float*>(smem_raw + WORKB);      // [9][64]
+    float* s_co = s_w2 + 9 * C;                            // mean|invstd|k1|c1|c2|mean_lo|c1_lo
+    float* s_ci = s_co + 7 * C;                            // mean|scale|beta|invstd|mean_lo
+    double* s_bst = reinterpret_cast<double*>(s_ci + 5 * C);       // [2 pixel halves][2][64]
+    float* s_b1 = reinterpret_cast<float*>(s_bst + 2 * 2 * C);     // [64] pointwise bias
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_b1 + C);            // [IP] packed mode: pixel is real
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it lives in SGPRs
+    const int l15 = lane & 15, g = lane >> 4;
+    const int H = d.H, W = d.W;
+    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
+    const bool bn_out = d.out_has_bn != 0;
+    const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
+    const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
+#ifdef DP_BWD_PROF
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
+    const int tiles_x = ((PACKED ? pk.CW : W) + TW - 1) / TW, tiles_y = ((PACKED ? pk.CH : H) + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int ntiles = PACKED ? tiles_img : d.N * tiles_img;
+    auto inside = [&](int ip, int y, int x) {
+        if constexpr (PACKED) return s_in[ip] != 0;
+        else return y < H && x < W;
+    };
+
+    // ---- prefetch registers (next tile): raw dy / z_out over the halo, x over the interior -- as in dp_bwd_kernel
+    float4 pdy[NDZ];
+    act_raw4 pz[NDZ], px[NX];
+    unsigned okmask = 0;
+    static_assert(!(POOLDY && PACKED), "pooled dy: unpacked levels only");
+    unsigned pid[POOLDY ? NDZ : 1];
+    unsigned posmask = 0;
+    const int Wq = W >> 1;
+    const unsigned pooledbytes = (unsigned)((H >> 1) * Wq * C) * 4u;
+    const unsigned dybytes = (unsigned)(H * W * C) * 4u, zbytes = (unsigned)(H * W * C) * ACT_B;
+    const unsigned xbytes = (unsigned)(H * W * C) * ACT_B, dxbytes = (unsigned)(H * W * C) * 4u;
+    auto issue = [&](int t, auto part_c) {
+        constexpr int PART = decltype(part_c)::value;
+        const int tid = opaque((int)threadIdx.x);
+        const int och4 = tid % C4;
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        const unsigned dyrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * 4u : dybytes;
+        const unsigned zrange = PACKED ? (unsigned)d.N * (unsigned)d.z_img_stride * ACT_B : zbytes;
+        const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * ACT_B : xbytes;
+        const size_t zbase = PACKED ? (size_t)0 : (size_t)n * d.z_img_stride;
+        const size_t xbase = PACKED ? (size_t)0 : (size_t)n * d.x_img_stride;
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.dy) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : zbase), 0, POOLDY ? pooledbytes : dyrange, 0x00020000);
+        const auto r_id = __builtin_amdgcn_make_buffer_rsrc(
+            d.pool_idx + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0,
+            POOLDY ? pooledbytes / 4u : 0u, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xrange, 0x00020000);
+        if (PART <= 0) { okmask = 0; posmask = 0; }
+#pragma unroll
+        for (int i = 0; i < NDZ; ++i) {
+            if (PART >= 0 && PART != 1 + (3 * i) / NDZ) continue;
+            const int hp = tid / C4 + PSTEP * i;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            bool ok;
+            unsigned eo;
+            if constexpr (PACKED) {
+                int pn, py, pxx;
+                ok = hp < HP && pk_locate(pk, y, x, pn, py, pxx);
+                eo = (unsigned)(pn * d.z_img_stride + (py * W + pxx) * C + och4 * 4);
+            } else {
+                ok = hp < HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                eo = (unsigned)((y * W + x) * C + och4 * 4);
+            }
+            okmask |= ok ? (1u << i) : 0u;
+            if constexpr (POOLDY) {
+                const unsigned eq = (unsigned)(((y >> 1) * Wq + (x >> 1)) * C + och4 * 4);
+                posmask |= (unsigned)(((y & 1) << 1) | (x & 1)) << (2 * i);
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+                pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
+            } else {
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dyrange, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+            }
+            pz[i] = act_raw4{};
+            if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zrange);
+            if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (PART > 0) continue;
+            const int ip = tid / C4 + PSTEP * i;
+            const int y = y0 + ip / TW, x = x0 + ip % TW;
+            unsigned off;
+            if constexpr (PACKED) {
+                int pn, py, pxx;
+                off = pk_locate(pk, y, x, pn, py, pxx)
+                          ? (unsigned)(pn * d.x_img_stride + (py * W + pxx) * C + och4 * 4) * ACT_B : xrange;
+            } else {
+                off = (y < H && x < W) ? (unsigned)((y * W + x) * C + och4 * 4) * ACT_B : xbytes;
+            }
+            px[i] = act_bufld4(r_x, off);
+            if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using All = std::integral_constant<int, -1>;
+    int t = first_tile();
+    if (t < ntiles) issue(t, All{});
+
+    // ---- this wave's weight fragments, straight from global memory into registers ------------------------------
+    // p = a * W1^T and da = dp * W1: wave `wid` owns output-channel tile nt = wid & 3 of both GEMMs and the pixel
+    // tiles 4 * (wid >> 2) .. + 3.  B operand of v_mfma_f32_16x16x32_bf16: lane (l15, g) supplies column l15,
+    // k = 32 kb + 8 g .. + 7.
+    const int nt = wid & 3, mh = wid >> 2;
+    u32x4 w1h[2], w1l[2], wth[2], wtl[2];
+    {
+        const int co = nt * 16 + l15;             // p GEMM: column = output channel, k = input channel
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 a = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g);
+            const float4 b = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g + 4);
+            const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const Split8 sp = split8(w8);
+            w1h[kb] = sp.hi; w1l[kb] = sp.lo;
+        }
+        const int ci = nt * 16 + l15;             // da GEMM: column = input channel, k = output channel
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = d.w_pw[(32 * kb + 8 * g + j) * C + ci];
+            const Split8 sp = split8(w8);
+            wth[kb] = sp.hi; wtl[kb] = sp.lo;
+        }
+    }
+    for (int c = tid; c < C; c += BWD_THREADS) s_b1[c] = d.b_pw[c];
+    for (int i = tid; i < C * 9; i += BWD_THREADS) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
+    for (int c = tid; c < C; c += BWD_THREADS) {
+        if (bn_out) {
+            const BNBwd k = bn_bwd_coef(d.out_bn, C, c);
+            s_co[c] = k.mean; s_co[C + c] = k.invstd; s_co[2 * C + c] = k.k1;
+            s_co[3 * C + c] = k.c1; s_co[4 * C + c] = k.c2;
+            s_co[5 * C + c] = k.mean_lo; s_co[6 * C + c] = k.c1_lo;
+        } else {
+            s_co[c] = 0.f; s_co[C + c] = 0.f;
+            s_co[2 * C + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
+            s_co[3 * C + c] = 0.f; s_co[4 * C + c] = 0.f;
+            s_co[5 * C + c] = 0.f; s_co[6 * C + c] = 0.f;
+        }
+        if (bn_in) {
+            const BNCoef k = bn_coef(d.in_bn, C, c);
+            s_ci[c] = k.mean; s_ci[C + c] = k.scale; s_ci[2 * C + c] = k.beta;
+            s_ci[3 * C + c] = k.invstd; s_ci[4 * C + c] = k.mean_lo;
+        } else {
+            s_ci[c] = 0.f; s_ci[C + c] = 1.f; s_ci[2 * C + c] = 0.f; s_ci[3 * C + c] = 1.f; s_ci[4 * C + c] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- persistent accumulators ----------------------------------------------------------------------------------
+    float4 gw2[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gw2[k] = make_float4(0, 0, 0, 0);
+    float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
+    // dW1 (K = pixels): waves 0-3 take pixels 0-63, waves 4-7 pixels 64-127; wave group (wid & 3) owns the
+    // 2 x 2 block of 16 x 16 tiles  ci tiles 2 * (grp >> 1) + {0, 1}  x  co tiles 2 * (grp & 1) + {0, 1}
+    f32x4 gw1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int w1_ct = 2 * ((wid & 3) >> 1), w1_ot = 2 * (wid & 1), w1_ks = wid >> 2;
+    // producer's BN-backward sums: fp64, one private LDS slot per (pixel half, channel) -- wave (mh, nt) owns
+    // channels nt * 16 .. + 15 of half mh, so plain read-modify-write (as registers they cost 4 VGPRs)
+    for (int i = tid; i < 2 * 2 * C; i += BWD_THREADS) s_bst[i] = 0.0;
+
+    const bool pf_on = !(abl & 32);
+#ifdef DP_BWD_PROF
+    // phase counters live in LDS (as registers they change the allocation of the kernel they measure)
+    const bool prof_on = (unsigned long long)d.prof >= 4096ull;
+    unsigned long long* s_prof = reinterpret_cast<unsigned long long*>(s_in + IP);
+    if (tid == 0) {
+        for (int q = 0; q < 6; ++q) s_prof[q] = 0;
+        s_prof[7] = __builtin_readcyclecounter();
+        s_prof[6] = s_prof[7] - prof_t0;
+    }
+#endif
+    for (; t < ntiles; t += gridDim.x) {
+        const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
+        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+
+        // ---- stage: dz = BN backward of this unit's own BN -> LDS; x raw -> LDS; a = T(x) split -> planes ---------
+        {
+            const int tid = opaque((int)threadIdx.x);
+            const int och4 = tid % C4;
+            const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
+            const float4 o_inv = *reinterpret_cast<float4*>(s_co + C + och4 * 4);
+            const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * C + och4 * 4);
+            const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * C + och4 * 4);
+            const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * C + och4 * 4);
+            const float4 o_ml = *reinterpret_cast<float4*>(s_co + 5 * C + och4 * 4);
+            const float4 o_cl = *reinterpret_cast<float4*>(s_co + 6 * C + och4 * 4);
+            const int hp0 = tid / C4;
+#pragma unroll
+            for (int i = 0; i < NDZ; ++i) {
+                const int hp = hp0 + PSTEP * i;
+                if ((i + 1) * PSTEP <= HP || hp < HP) {
+                    float4 dy = pdy[i];
+                    const float4 z = act_unpack(pz[i]);
+                    if constexpr (POOLDY) {
+                        const unsigned id = pid[i], pos = (posmask >> (2 * i)) & 3u;
+                        dy.x = (id & 0xffu) == pos ? dy.x : 0.0f;
+                        dy.y = ((id >> 8) & 0xffu) == pos ? dy.y : 0.0f;
+                        dy.z = ((id >> 16) & 0xffu) == pos ? dy.z : 0.0f;
+                        dy.w = (id >> 24) == pos ? dy.w : 0.0f;
+                    }
+                    float4 v;
+                    if (bn_out) {
+                        const bool ok = (okmask >> i) & 1u;
+                        v.x = ok ? bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x) : 0.0f;
+                        v.y = ok ? bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y) : 0.0f;
+                        v.z = ok ? bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z) : 0.0f;
+                        v.w = ok ? bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w) : 0.0f;
+                    } else {
+                        v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
+                    }
+                    *reinterpret_cast<float4*>(s_dz + hp * C + och4 * 4) = v;
+                }
+            }
+            if constexpr (PACKED) {
+                for (int ip = tid; ip < IP; ip += BWD_THREADS) {
+                    int pn, py, pxx;
+                    s_in[ip] = pk_locate(pk, y0 + ip / TW, x0 + ip % TW, pn, py, pxx) ? 1 : 0;
+                }
+            }
+            const float4 i_mean = *reinterpret_cast<float4*>(s_ci + och4 * 4);
+            const float4 i_scale = *reinterpret_cast<float4*>(s_ci + C + och4 * 4);
+            const float4 i_beta = *reinterpret_cast<float4*>(s_ci + 2 * C + och4 * 4);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int ip = hp0 + PSTEP * i;
+                const float4 xv = act_unpack(px[i]);
+                *reinterpret_cast<float4*>(s_x + ip * C + och4 * 4) = xv;
+                unsigned h0, l0, h1, l1;
+                split2(tin(xv.x, i_mean.x, i_scale.x, i_beta.x, relu_floor),
+                       tin(xv.y, i_mean.y, i_scale.y, i_beta.y, relu_floor), h0, l0);
+                split2(tin(xv.z, i_mean.z, i_scale.z, i_beta.z, relu_floor),
+                       tin(xv.w, i_mean.w, i_scale.w, i_beta.w, relu_floor), h1, l1);
+                unsigned char* ap = s_a + plane_off(ip, och4 >> 1) + (och4 & 1) * 8;
+                *reinterpret_cast<u32x2*>(ap) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(ap + PLANE) = u32x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        DP_BWD64_STAMP(0);
+        const bool more = t + (int)gridDim.x < ntiles && pf_on;
+
+        // ---- p = a * W1^T + b1: this wave's 16 output channels on 4 pixel tiles -------------------------------------
+        if (!(abl & 1)) {
+            const int l15o = opaque(l15), go = opaque(g);
+            const unsigned char* abase = s_a + (mh * 64 + l15o) * (C * 2);
+            const int sw = l15o & 7;
+            const float bias1 = s_b1[nt * 16 + l15o];
+            f32x4 acc[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {           // four independent accumulator chains per k block
+                u32x4 ah[4], al[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const unsigned char* ap = abase + mi * 16 * (C * 2) + (((4 * kb + go) ^ sw) << 4);
+                    ah[mi] = *reinterpret_cast<const u32x4*>(ap);
+                    al[mi] = *reinterpret_cast<const u32x4*>(ap + PLANE);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
+                    const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
+                    s_p[ip * C + nt * 16 + l15o] = in ? acc[mi][r] + bias1 : 0.0f;
+                }
+        }
+        __syncthreads();
+        DP_BWD64_STAMP(1);
+        // next tile's loads go out in four pieces from here on (the p GEMM above runs with no load in flight: a
+        // CU cannot keep a whole tile's 124 KB in flight, and the in-order vector-memory queue would hold any
+        // scratch access behind them)
+        if (more) issue(t + gridDim.x, std::integral_constant<int, 0>{});
+
+        // ---- depthwise backward on the VALU (sliding window over a 4-row column); dp stays in registers -------------
+        float4 dp[4];
+        int d_pix0;
+        {
+            const int tv = opaque((int)threadIdx.x);
+            const int cq = tv % C4, pg = tv / C4;
+            const int vtx = pg % TW, vr0 = (pg / TW) * 4;
+            d_pix0 = vr0 * TW + vtx;
+            const float* zb = s_dz + (vr0 * HW_ + vtx) * C + cq * 4;
+            const float* pb = s_p + (vr0 * TW + vtx) * C + cq * 4;
+            const float* wb = s_w2 + cq * 4;
+            float4 pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pv[r] = *reinterpret_cast<const float4*>(pb + r * TW * C);
+                dp[r] = make_float4(0, 0, 0, 0);
+            }
+            if (!(abl & 2)) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float4 wk[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        wk[a] = *reinterpret_cast<const float4*>(wb + (8 - (3 * a + b)) * C);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float4 z4 = *reinterpret_cast<const float4*>(zb + (j * HW_ + b) * C);
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const int r = j - a;
+                            if (r < 0 || r >= 4) continue;
+                            const int k = 8 - (3 * a + b);
+                            dp[r].x = fmaf(z4.x, wk[a].x, dp[r].x); dp[r].y = fmaf(z4.y, wk[a].y, dp[r].y);
+                            dp[r].z = fmaf(z4.z, wk[a].z, dp[r].z); dp[r].w = fmaf(z4.w, wk[a].w, dp[r].w);
+                            gw2[k].x = fmaf(pv[r].x, z4.x, gw2[k].x); gw2[k].y = fmaf(pv[r].y, z4.y, gw2[k].y);
+                            gw2[k].z = fmaf(pv[r].z, z4.z, gw2[k].z); gw2[k].w = fmaf(pv[r].w, z4.w, gw2[k].w);
+                            if (a == 1 && b == 1) {
+                                gb2.x += z4.x; gb2.y += z4.y; gb2.z += z4.z; gb2.w += z4.w;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = inside((vr0 + r) * TW + vtx, y0 + vr0 + r, x0 + vtx);
+                if (!in) dp[r] = make_float4(0, 0, 0, 0);
+                gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
+            }
+        }
+        if (more) issue(t + gridDim.x, std::integral_constant<int, 1>{});
+        __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
+        {
+            const int cq = opaque((int)threadIdx.x) % C4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = d_pix0 + r * TW;
+                unsigned h0, l0, h1, l1;
+                split2(dp[r].x, dp[r].y, h0, l0);
+                split2(dp[r].z, dp[r].w, h1, l1);
+                unsigned char* q = s_d + plane_off(pix, cq >> 1) + (cq & 1) * 8;
+                *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(q + PLANE) = u32x2{l0, l1};
+            }
+        }
+        __syncthreads();
+        DP_BWD64_STAMP(2);
+        if (more) issue(t + gridDim.x, std::integral_constant<int, 2>{});
+
+        // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
+        // k index of lane group G, element e (0..7): pixel 32 kb + 4 * (4 (G >> 1) + 2 (e >> 2) + (G & 1)) + (e & 3) --
+        // the two 4-pixel blocks a 32-lane half reads in one instruction then differ in pixel bit 2, which the
+        // plane swizzle turns into different banks (any k order is valid as long as A and B agree)
+        if (!(abl & 4)) {
+            const int lo_ = opaque(lane);
+            const int i16 = lo_ & 15, G = lo_ >> 4;
+            const int prow = 4 * (4 * (G >> 1) + (G & 1)) + (i16 >> 2);          // + 8 for the second read
+            const int sub = i16 & 3;                                              // 4-channel quad inside the 16-channel tile
+#pragma unroll
+            for (int kbi = 0; kbi < 2; ++kbi) {
+                const int p0 = 64 * w1_ks + 32 * kbi + prow;
+                u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int tI = 0; tI < 2; ++tI) {
+                    const int chA = 2 * (w1_ct + tI) + (sub >> 1), chB = 2 * (w1_ot + tI) + (sub >> 1);
+                    const unsigned char* a0 = s_a + plane_off(p0, chA) + (sub & 1) * 8;
+                    const unsigned char* a1 = s_a + plane_off(p0 + 8, chA) + (sub & 1) * 8;
+                    const unsigned char* b0 = s_d + plane_off(p0, chB) + (sub & 1) * 8;
+                    const unsigned char* b1 = s_d + plane_off(p0 + 8, chB) + (sub & 1) * 8;
+                    const u32x2 ah0 = tr_read(a0), ah1 = tr_read(a1), al0 = tr_read(a0 + PLANE), al1 = tr_read(a1 + PLANE);
+                    const u32x2 bh0 = tr_read(b0), bh1 = tr_read(b1), bl0 = tr_read(b0 + PLANE), bl1 = tr_read(b1 + PLANE);
+                    ah[tI] = u32x4{ah0.x, ah0.y, ah1.x, ah1.y}; al[tI] = u32x4{al0.x, al0.y, al1.x, al1.y};
+                    bh[tI] = u32x4{bh0.x, bh0.y, bh1.x, bh1.y}; bl[tI] = u32x4{bl0.x, bl0.y, bl1.x, bl1.y};
+                }
+                gw1[0] = mfma3r(ah[0], al[0], bh[0], bl[0], gw1[0]);
+                gw1[1] = mfma3r(ah[0], al[0], bh[1], bl[1], gw1[1]);
+                gw1[2] = mfma3r(ah[1], al[1], bh[0], bl[0], gw1[2]);
+                gw1[3] = mfma3r(ah[1], al[1], bh[1], bl[1], gw1[3]);
+            }
+        }
+        DP_BWD64_STAMP(3);
+        if (more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
+
+        // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
+        {
+            const int l15o = opaque(l15), go = opaque(g);
+            const unsigned char* dbase = s_d + (mh * 64 + l15o) * (C * 2);
+            const int sw = l15o & 7;
+            const int c = nt * 16 + l15o;
+            const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
+            const float m_lo = s_ci[4 * C + c];
+            float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(abl & 8)) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const unsigned char* q = dbase + mi * 16 * (C * 2) + (((4 * kb + go) ^ sw) << 4);
+                        const u32x4 ph = *reinterpret_cast<const u32x4*>(q);
+                        const u32x4 pl = *reinterpret_cast<const u32x4*>(q + PLANE);
+                        da = mfma3r(ph, pl, wth[kb], wtl[kb], da);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
+                    float v = da[r];
+                    if (bn_in) {
+                        const float xr = s_x[ip * C + c];
+                        const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
+                        v = (in && fmaf(xr - m_mean, m_scale, m_beta) > 0.0f) ? v : 0.0f;      // ReLU mask
+                        t0 += v;
+                        t1 = fmaf(v, bn_center(xr, m_mean, m_lo) * m_inv, t1);
+                    }
+                    s_p[ip * C + c] = v;
+                }
+            }
+            // 16 pixels x 4 tiles per lane in fp32 (a handful of terms), then fp64 for the long, heavily
+            // cancelling accumulation over the whole tensor
+            if (bn_in) {
+                t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64);
+                t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
+                if (go == 0) {
+                    double* bs = s_bst + (mh * 2) * C + c;
+                    bs[0] += (double)t0;
+                    bs[C] += (double)t1;
+                }
+            }
+        }
+        __syncthreads();
+        DP_BWD64_STAMP(4);
+
+        // ---- dx store (coalesced rows of s_p) --------------------------------------------------------------------------
+        if (d.dx && !(abl & 16)) {
+            const int tid = opaque((int)threadIdx.x);
+            const int ich4 = tid % C4;
+            const unsigned xrange = PACKED ? (unsigned)d.N * (unsigned)d.x_img_stride * 4u : dxbytes;
+            const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(
+                d.dx + (PACKED ? (size_t)0 : (size_t)n * d.x_img_stride), 0, xrange, 0x00020000);
+            unsigned off[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int ip = tid / C4 + PSTEP * i;
+                const int y = y0 + ip / TW, x = x0 + ip % TW;
+                if constexpr (PACKED) {
+                    int pn, py, pxx;
+                    off[i] = pk_locate(pk, y, x, pn, py, pxx)
+                                 ? (unsigned)(pn * d.x_img_stride + (py * W + pxx) * C + ich4 * 4) * 4u : xrange;
+                } else {
+                    off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * C + ich4 * 4) * 4u : dxbytes;
+                }
+            }
+            if (d.accumulate_dx) {
+                u32x4 old[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) old[i] = __builtin_amdgcn_raw_buffer_load_b128(r_dx, off[i], 0, 0);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const int ip = tid / C4 + PSTEP * i;
+                    float4 v = *reinterpret_cast<const float4*>(s_p + ip * C + ich4 * 4);
+                    const float4 o = *reinterpret_cast<const float4*>(&old[i]);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const int ip = tid / C4 + PSTEP * i;
+                    const float4 v = *reinterpret_cast<const float4*>(s_p + ip * C + ich4 * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                }
+            }
+        }
+        DP_BWD64_STAMP(5);
+        // no barrier here: the next stage writes the halo / x / a planes (all read before the barrier above) and
+        // s_p is next written by the p GEMM, one barrier later
+    }
+
+    // ============ flush per-workgroup partial sums ================================================================
+#ifdef DP_BWD_PROF
+    if (prof_on && threadIdx.x == 0)
+        for (int q = 0; q < 7; ++q) d.prof[blockIdx.x * 8 + q] = s_prof[q];
+    const unsigned long long prof_t1 = __builtin_readcyclecounter();
+#endif
+    __syncthreads();                                     // the last tile's dx rows have been read
+    float* row = d.wgrad_partials + (size_t)blockIdx.x * WROW;
+    float* sm = reinterpret_cast<float*>(smem_raw);
+    float* s_gw1 = sm;                                   // [KSPLIT][COUT][CIN]
+    float* red = sm + KSPLIT * C * C;                    // [BWD_THREADS][24]
+    {
+        float* pl = s_gw1 + w1_ks * C * C;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)      // D layout: column = co (B operand tile), row = ci (A operand tile)
+                    pl[((w1_ot + i) * 16 + l15) * C + (w1_ct + j) * 16 + 4 * g + r] = gw1[j * 2 + i][r];
+    }
+    float4* my = reinterpret_cast<float4*>(red + tid * 24);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) my[k] = gw2[k];
+    __syncthreads();
+    for (int i = tid; i < C * C; i += BWD_THREADS) row[i] = s_gw1[i] + s_gw1[C * C + i];
+    constexpr int PG = BWD_THREADS / C4;
+    auto reduce_pass = [&](int ps, int nslot) {
+        for (int o = tid; o < C * nslot; o += BWD_THREADS) {
+            const int c = o / nslot, k = o - c * nslot;
+            const int q = c >> 2, e = c & 3;
+            float v = 0.0f;
+            for (int p = 0; p < PG; ++p) v += red[(p * C4 + q) * 24 + k * 4 + e];
+            const int slot = ps * 6 + k;
+            if (slot < 9) row[C * C + C + c * 9 + slot] = v;
+            else if (slot == 9) row[C * C + c] = v;
+            else row[C * C + C + C * 9 + c] = v;
+        }
+    };
+    reduce_pass(0, 6);
+    if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * C) {
+        const int which = tid / C, c = tid % C;
+        atomic_add_f64(d.in_bn.bstats + tid, s_bst[which * C + c] + s_bst[(2 + which) * C + c]);
+    }
+    __syncthreads();
+    my[0] = gw2[6]; my[1] = gw2[7]; my[2] = gw2[8]; my[3] = gb1; my[4] = gb2;
+    __syncthreads();
+    reduce_pass(1, 5);
+#ifdef DP_BWD_PROF
+    if (prof_on && threadIdx.x == 0) d.prof[blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - prof_t1;
+#endif
+}
+
+template <bool PACKED, bool POOLDY>
+int launch_dp_bwd64(const YunetDP* d, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd64_kernel<PACKED, POOLDY>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd64::SMEM);
+        attr_set = true;
+    }
+    PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
+    pk.on = PACKED ? 1 : 0;
+    if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
+    const int tiles = PACKED ? ((pk.CW + bwd64::TW - 1) / bwd64::TW) * ((pk.CH + bwd64::TH - 1) / bwd64::TH)
+                             : d->N * ((d->W + bwd64::TW - 1) / bwd64::TW) * ((d->H + bwd64::TH - 1) / bwd64::TH);
+    int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
+    if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
+    if (grid < 1) return YUNET_EINVAL;
+    hipLaunchKernelGGL((dp_bwd64_kernel<PACKED, POOLDY>), dim3(grid), dim3(BWD_THREADS), bwd64::SMEM, stream, *d, pk);
+    return hip_status();
+}
+
 // ----------------------------------------------------------------------------- stem wgrad
 #define SB_TW 32
 #define SB_TH 8
@@ -1371,7 +2018,8 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
         if (d->cin == 32) return launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
-        return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
+        if (getenv("YUNET_BWD64_R2")) return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
+        return launch_dp_bwd64<false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
@@ -1380,12 +2028,17 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     // 64 -> 64 units: split-bf16 GEMMs (gradients only); YUNET_BWD_FP32MMA=1 keeps the exact-fp32
     // matrix instruction (A/B measurements, tools/kbench.py)
     const bool f32mma = getenv("YUNET_BWD_FP32MMA") != nullptr;
+    // YUNET_BWD64_R2=1: the round-2 split-bf16 kernel (template above) instead of dp_bwd64 (A/B runs)
+    const bool r2 = getenv("YUNET_BWD64_R2") != nullptr;
     if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout)) {           // 20x20 / 10x10 levels: packed canvas
-        if (d->cout == 64)
-            return f32mma ? launch_dp_bwd<64, 64, 8, 16, true>(d, s) : launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s);
+        if (d->cout == 64) {
+            if (f32mma) return launch_dp_bwd<64, 64, 8, 16, true>(d, s);
+            return r2 ? launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s) : launch_dp_bwd64<true, false>(d, s);
+        }
         return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
     }
-    if (d->cin == 64 && d->cout == 64 && !f32mma) return launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s);
+    if (d->cin == 64 && d->cout == 64 && !f32mma)
+        return r2 ? launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s) : launch_dp_bwd64<false, false>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)
