@@ -986,27 +986,52 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
 //   * five barriers per tile.
 // LDS: dz halo 45 KB | raw x 32 KB | p / dx staging 32 KB | a planes 32 KB | small tables; the dp planes alias the
 // dz halo (dead after the depthwise phase).
-namespace bwd64 {
-constexpr int C = 64, C4 = 16, TH = 8, TW = 16, HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_, IP = TH * TW;
-constexpr int NDZ = (HP * C4 + BWD_THREADS - 1) / BWD_THREADS;     // 6 (dy, z) float4 pairs per thread
-constexpr int NX = (IP * C4) / BWD_THREADS;                        // 4 x float4 per thread
-constexpr int PSTEP = BWD_THREADS / C4;                            // 32 halo pixels between a thread's slots
-constexpr int PLANE = IP * C * 2;                                  // one bf16 plane: 16 KB
-constexpr int OFF_DZ = 0;                                          // float [HP][64]; later dp planes hi | lo
-constexpr int OFF_X = OFF_DZ + HP * C * 4;                         // float [IP][64] raw x
-constexpr int OFF_P = OFF_X + IP * C * 4;                          // float [IP][64] p, later the masked dx
-constexpr int OFF_A = OFF_P + IP * C * 4;                          // bf16 planes hi | lo of a = T(x)
-constexpr int WORKB = OFF_A + 2 * PLANE;
-constexpr int PAR_F = 9 * C + 7 * C + 5 * C;                       // w2 | out-bn | in-bn (floats)
-#ifdef DP_BWD_PROF
-constexpr int SMEM = WORKB + PAR_F * 4 + 2 * 2 * C * 8 + C * 4 + IP + 64;
+// one activation element through a buffer descriptor, widened to fp32
+template <typename R>
+__device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
+#ifdef YUNET_ACT_BF16
+    return __uint_as_float(((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, byte_off, 0, 0)) << 16);
 #else
-constexpr int SMEM = WORKB + PAR_F * 4 + 2 * 2 * C * 8 + C * 4 + IP;   // + fp64 sums of the two pixel halves + bias + validity bytes
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0));
 #endif
+}
+namespace bwd64 {
+constexpr int C = 64, C4 = 16;
+constexpr int PLANE_PX = 128;      // (pixels of the largest tile: plane_off() only needs the row pitch)
+// NW = waves per workgroup: 8 -> 8 x 16 pixel tiles, one workgroup (149 KB of LDS) per CU;
+//                           4 -> 8 x 8 pixel tiles, TWO independent workgroups (80 KB each) per CU, whose phases
+//                                interleave on the SIMDs instead of marching in lockstep through five barriers
+template <int NW>
+struct Geo {
+    static constexpr int NT = NW * 64;
+    static constexpr int TH = 8, TW = 2 * NW, HW_ = TW + 2, HH_ = TH + 2, HP = HH_ * HW_, IP = TH * TW;
+    static constexpr int PSTEP = NT / C4;                              // halo pixels per pass of the workgroup
+    // (dy, z) float4 pairs per thread.  NW = 8: 180 halo pixels = 5 full passes + a partial one;
+    // NW = 4: 100 = 6 full passes + 4 pixels, which are loaded as ONE float per thread (REM)
+    static constexpr int NDZ = NW == 8 ? (HP + PSTEP - 1) / PSTEP : HP / PSTEP;
+    static constexpr bool REM = NW == 4;
+    static constexpr int REM_HP0 = NDZ * PSTEP;                        // first halo pixel of the remainder
+    static constexpr int NX = (IP * C4) / NT;                          // x float4 per thread
+    static constexpr int PLANE = IP * C * 2;                           // one bf16 plane
+    static constexpr int OFF_DZ = 0;                                   // float [HP][64]; later dp planes hi | lo
+    static constexpr int OFF_X = OFF_DZ + HP * C * 4;                  // float [IP][64] raw x
+    static constexpr int OFF_P = OFF_X + IP * C * 4;                   // float [IP][64] p, later the masked dx
+    static constexpr int OFF_A = OFF_P + IP * C * 4;                   // bf16 planes hi | lo of a = T(x)
+    static constexpr int WORKB = OFF_A + 2 * PLANE;
+    static constexpr int PAR_F = 9 * C + 7 * C + 5 * C + C;            // w2 | out-bn | in-bn | b1 (floats)
+    static constexpr int MH = NW / 4;                                  // pixel halves (p / da GEMM: 4 pixel tiles per wave)
+#ifdef DP_BWD_PROF
+    static constexpr int SMEM = WORKB + PAR_F * 4 + MH * 2 * C * 8 + IP + 64;
+#else
+    static constexpr int SMEM = WORKB + PAR_F * 4 + MH * 2 * C * 8 + IP;   // + fp64 sums per pixel half + validity bytes
+#endif
+    static constexpr int KSPLIT = NW / 4;                              // dW1: pixels 64 ks .. 64 ks + 63 per wave quad
+    static_assert(2 * PLANE <= HP * C * 4, "dp planes alias the dz halo");
+    static_assert((size_t)KSPLIT * C * C * 4 + (size_t)NT * 24 * 4 <= (size_t)WORKB, "flush area");
+    static_assert(!REM || (HP - REM_HP0) * C == NT, "remainder: one float per thread");
+    static_assert(IP % 64 == 0 && NX * NT == IP * C4, "tile mapping");
+};
 constexpr int WROW = C * C + C + C * 9 + C;
-constexpr int KSPLIT = 2;                                          // dW1: waves 0-3 pixels 0-63, waves 4-7 pixels 64-127
-static_assert(2 * PLANE <= HP * C * 4, "dp planes alias the dz halo");
-static_assert((size_t)KSPLIT * C * C * 4 + (size_t)BWD_THREADS * 24 * 4 <= (size_t)WORKB, "flush area");
 // byte offset of channels 8*chunk .. 8*chunk+7 of pixel `pix` inside a plane (16-byte chunks, XOR-swizzled so
 // that both the row-wise 16-byte operand reads and the transposing reads are bank-conflict free)
 __device__ __forceinline__ int plane_off(int pix, int chunk) { return pix * (C * 2) + ((chunk ^ (pix & 7)) << 4); }
@@ -1028,9 +1053,14 @@ __device__ __forceinline__ f32x4 mfma3r(const u32x4 ah, const u32x4 al, const u3
 }
 }  // namespace bwd64
 
-template <bool PACKED, bool POOLDY>
-__global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
+template <int NW, bool PACKED, bool POOLDY>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))     // 256 registers per lane: 8 waves per CU
+void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     using namespace bwd64;
+    using G = Geo<NW>;
+    constexpr int NT = G::NT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, IP = G::IP, NDZ = G::NDZ, NX = G::NX;
+    constexpr int PSTEP = G::PSTEP, PLANE = G::PLANE, OFF_DZ = G::OFF_DZ, OFF_X = G::OFF_X, OFF_P = G::OFF_P;
+    constexpr int OFF_A = G::OFF_A, WORKB = G::WORKB, KSPLIT = G::KSPLIT, MH = G::MH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* s_dz = reinterpret_cast<float*>(smem_raw + OFF_DZ);
     float* s_x = reinterpret_cast<float*>(smem_raw + OFF_X);
@@ -1038,11 +1068,11 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     unsigned char* s_a = smem_raw + OFF_A;                 // planes of a: hi at 0, lo at PLANE
     unsigned char* s_d = smem_raw + OFF_DZ;                // planes of dp (alias the dz halo)
     float* s_w2 = reinterpret_cast<float*>(smem_raw + WORKB);      // [9][64]
-    float* s_co = s_w2 + 9 * C;                            // mean|invstd|k1|c1|c2|mean_lo|c1_lo
+    float* s_co = s_w2 + 9 * C;                            // folded BN backward of the unit's own BN: A|B|Dh|Dl (+3 spare rows)
     float* s_ci = s_co + 7 * C;                            // mean|scale|beta|invstd|mean_lo
-    double* s_bst = reinterpret_cast<double*>(s_ci + 5 * C);       // [2 pixel halves][2][64]
-    float* s_b1 = reinterpret_cast<float*>(s_bst + 2 * 2 * C);     // [64] pointwise bias
-    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_b1 + C);            // [IP] packed mode: pixel is real
+    float* s_b1 = s_ci + 5 * C;                            // [64] pointwise bias
+    double* s_bst = reinterpret_cast<double*>(s_b1 + C);   // [MH pixel halves][2][64]
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_bst + MH * 2 * C);  // [IP] packed mode: pixel is real
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it lives in SGPRs
@@ -1051,7 +1081,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
     const bool bn_out = d.out_has_bn != 0;
     const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
-    const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof : 0u;
+    // debug: prof < 4096 is an ablation bit mask; a -DDP_BWD_PROF build also takes the mask from the low 6 bits of
+    // the (256-byte aligned) counter pointer, so that ablated runs can be profiled per phase
+    const unsigned abl = (unsigned long long)d.prof < 4096ull ? (unsigned)(unsigned long long)d.prof
+#ifdef DP_BWD_PROF
+                                                              : (unsigned)((unsigned long long)d.prof & 63ull);
+    unsigned long long* const prof_out = reinterpret_cast<unsigned long long*>((unsigned long long)d.prof & ~63ull);
+#else
+                                                              : 0u;
+#endif
 #ifdef DP_BWD_PROF
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
@@ -1070,6 +1108,8 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     static_assert(!(POOLDY && PACKED), "pooled dy: unpacked levels only");
     unsigned pid[POOLDY ? NDZ : 1];
     unsigned posmask = 0;
+    float rem_dy = 0.0f, rem_z = 0.0f;        // NW = 4: the last 4 halo pixels, one float per thread
+    unsigned rem_id = 0;
     const int Wq = W >> 1;
     const unsigned pooledbytes = (unsigned)((H >> 1) * Wq * C) * 4u;
     const unsigned dybytes = (unsigned)(H * W * C) * 4u, zbytes = (unsigned)(H * W * C) * ACT_B;
@@ -1126,6 +1166,34 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
             if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zrange);
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (G::REM) {
+            if (PART < 0 || PART == 3) {
+                const int hp = G::REM_HP0 + tid / C, ch = tid % C;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                bool ok;
+                unsigned eo;
+                if constexpr (PACKED) {
+                    int pn, py, pxx;
+                    ok = pk_locate(pk, y, x, pn, py, pxx);
+                    eo = (unsigned)(pn * d.z_img_stride + (py * W + pxx) * C + ch);
+                } else {
+                    ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                    eo = (unsigned)((y * W + x) * C + ch);
+                }
+                okmask |= ok ? (1u << NDZ) : 0u;
+                if constexpr (POOLDY) {
+                    const unsigned eq = (unsigned)(((y >> 1) * Wq + (x >> 1)) * C + ch);
+                    posmask |= (unsigned)(((y & 1) << 1) | (x & 1)) << (2 * NDZ);
+                    rem_dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eq * 4u : pooledbytes, 0, 0));
+                    rem_id = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_id, ok ? eq : pooledbytes, 0, 0) & 0xffu;
+                } else {
+                    rem_dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eo * 4u : dyrange, 0, 0));
+                }
+                rem_z = 0.0f;
+                if (bn_out) rem_z = act_bufld1(r_z, ok ? eo * ACT_B : zrange);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             if (PART > 0) continue;
@@ -1173,19 +1241,24 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
             wth[kb] = sp.hi; wtl[kb] = sp.lo;
         }
     }
-    for (int c = tid; c < C; c += BWD_THREADS) s_b1[c] = d.b_pw[c];
-    for (int i = tid; i < C * 9; i += BWD_THREADS) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
-    for (int c = tid; c < C; c += BWD_THREADS) {
+    for (int c = tid; c < C; c += NT) s_b1[c] = d.b_pw[c];
+    for (int i = tid; i < C * 9; i += NT) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
+    for (int c = tid; c < C; c += NT) {
+        // dz = k1 * (dy - c1 - xhat * c2), xhat = (z - mean) * invstd, folded into  dz = A dy + B z + D  with
+        // A = k1, B = -k1 c2 invstd (rounded to fp32) and D = -A c1 - B mean evaluated in fp64 WITH the rounded
+        // B and carried as a (hi, lo) pair: the rounding of B then scales the centred term (z - mean) by 1 + 6e-8
+        // instead of shifting every dz of the channel by 6e-8 |B mean| -- the systematic offset that would break
+        // sum(dz) = 0 (bn_center in common.h) -- and the nine operations per element become two FMAs and an add
         if (bn_out) {
             const BNBwd k = bn_bwd_coef(d.out_bn, C, c);
-            s_co[c] = k.mean; s_co[C + c] = k.invstd; s_co[2 * C + c] = k.k1;
-            s_co[3 * C + c] = k.c1; s_co[4 * C + c] = k.c2;
-            s_co[5 * C + c] = k.mean_lo; s_co[6 * C + c] = k.c1_lo;
+            const float A = k.k1;
+            const float B = (float)(-(double)k.k1 * (double)k.c2 * (double)k.invstd);
+            const double D = -(double)A * ((double)k.c1 + (double)k.c1_lo) - (double)B * ((double)k.mean + (double)k.mean_lo);
+            const float Dh = (float)D;
+            s_co[c] = A; s_co[C + c] = B; s_co[2 * C + c] = Dh; s_co[3 * C + c] = (float)(D - (double)Dh);
         } else {
-            s_co[c] = 0.f; s_co[C + c] = 0.f;
-            s_co[2 * C + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
-            s_co[3 * C + c] = 0.f; s_co[4 * C + c] = 0.f;
-            s_co[5 * C + c] = 0.f; s_co[6 * C + c] = 0.f;
+            s_co[c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
+            s_co[C + c] = 0.f; s_co[2 * C + c] = 0.f; s_co[3 * C + c] = 0.f;
         }
         if (bn_in) {
             const BNCoef k = bn_coef(d.in_bn, C, c);
@@ -1202,7 +1275,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) gw2[k] = make_float4(0, 0, 0, 0);
     float4 gb2 = make_float4(0, 0, 0, 0), gb1 = make_float4(0, 0, 0, 0);
-    // dW1 (K = pixels): waves 0-3 take pixels 0-63, waves 4-7 pixels 64-127; wave group (wid & 3) owns the
+    // dW1 (K = pixels): wave quad ks = wid >> 2 takes pixels 64 ks .. 64 ks + 63; wave (wid & 3) of a quad owns the
     // 2 x 2 block of 16 x 16 tiles  ci tiles 2 * (grp >> 1) + {0, 1}  x  co tiles 2 * (grp & 1) + {0, 1}
     f32x4 gw1[4];
 #pragma unroll
@@ -1210,7 +1283,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     const int w1_ct = 2 * ((wid & 3) >> 1), w1_ot = 2 * (wid & 1), w1_ks = wid >> 2;
     // producer's BN-backward sums: fp64, one private LDS slot per (pixel half, channel) -- wave (mh, nt) owns
     // channels nt * 16 .. + 15 of half mh, so plain read-modify-write (as registers they cost 4 VGPRs)
-    for (int i = tid; i < 2 * 2 * C; i += BWD_THREADS) s_bst[i] = 0.0;
+    for (int i = tid; i < MH * 2 * C; i += NT) s_bst[i] = 0.0;
 
     const bool pf_on = !(abl & 32);
 #ifdef DP_BWD_PROF
@@ -1226,18 +1299,18 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     for (; t < ntiles; t += gridDim.x) {
         const int n = PACKED ? 0 : t / tiles_img, rr = t - n * tiles_img;
         const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
+        // every pixel of the tile is a real pixel (all tiles of an 80 x 80 map, and of a 40 x 40 one with 8 x 8
+        // tiles): the per-element validity tests -- hundreds of integer instructions per tile -- are skipped
+        const bool tile_full = !PACKED && y0 + TH <= H && x0 + TW <= W;
 
         // ---- stage: dz = BN backward of this unit's own BN -> LDS; x raw -> LDS; a = T(x) split -> planes ---------
         {
             const int tid = opaque((int)threadIdx.x);
             const int och4 = tid % C4;
-            const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
-            const float4 o_inv = *reinterpret_cast<float4*>(s_co + C + och4 * 4);
-            const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * C + och4 * 4);
-            const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * C + och4 * 4);
-            const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * C + och4 * 4);
-            const float4 o_ml = *reinterpret_cast<float4*>(s_co + 5 * C + och4 * 4);
-            const float4 o_cl = *reinterpret_cast<float4*>(s_co + 6 * C + och4 * 4);
+            const float4 o_a = *reinterpret_cast<float4*>(s_co + och4 * 4);
+            const float4 o_b = *reinterpret_cast<float4*>(s_co + C + och4 * 4);
+            const float4 o_dh = *reinterpret_cast<float4*>(s_co + 2 * C + och4 * 4);
+            const float4 o_dl = *reinterpret_cast<float4*>(s_co + 3 * C + och4 * 4);
             const int hp0 = tid / C4;
 #pragma unroll
             for (int i = 0; i < NDZ; ++i) {
@@ -1252,21 +1325,26 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
                         dy.z = ((id >> 16) & 0xffu) == pos ? dy.z : 0.0f;
                         dy.w = (id >> 24) == pos ? dy.w : 0.0f;
                     }
+                    // zero padding of dz: a slot outside the image loaded dy = z = 0, which the BN backward
+                    // would turn into D
+                    const bool ok = (okmask >> i) & 1u;
                     float4 v;
-                    if (bn_out) {
-                        const bool ok = (okmask >> i) & 1u;
-                        v.x = ok ? bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x) : 0.0f;
-                        v.y = ok ? bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y) : 0.0f;
-                        v.z = ok ? bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z) : 0.0f;
-                        v.w = ok ? bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w) : 0.0f;
-                    } else {
-                        v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
-                    }
+                    v.x = ok ? fmaf(o_a.x, dy.x, fmaf(o_b.x, z.x, o_dh.x)) + o_dl.x : 0.0f;
+                    v.y = ok ? fmaf(o_a.y, dy.y, fmaf(o_b.y, z.y, o_dh.y)) + o_dl.y : 0.0f;
+                    v.z = ok ? fmaf(o_a.z, dy.z, fmaf(o_b.z, z.z, o_dh.z)) + o_dl.z : 0.0f;
+                    v.w = ok ? fmaf(o_a.w, dy.w, fmaf(o_b.w, z.w, o_dh.w)) + o_dl.w : 0.0f;
                     *reinterpret_cast<float4*>(s_dz + hp * C + och4 * 4) = v;
                 }
             }
+            if constexpr (G::REM) {
+                const int hp = G::REM_HP0 + tid / C, ch = tid % C;
+                float dyv = rem_dy;
+                if constexpr (POOLDY) dyv = rem_id == ((posmask >> (2 * NDZ)) & 3u) ? dyv : 0.0f;
+                const bool ok = (okmask >> NDZ) & 1u;
+                s_dz[hp * C + ch] = ok ? fmaf(s_co[ch], dyv, fmaf(s_co[C + ch], rem_z, s_co[2 * C + ch])) + s_co[3 * C + ch] : 0.0f;
+            }
             if constexpr (PACKED) {
-                for (int ip = tid; ip < IP; ip += BWD_THREADS) {
+                for (int ip = tid; ip < IP; ip += NT) {
                     int pn, py, pxx;
                     s_in[ip] = pk_locate(pk, y0 + ip / TW, x0 + ip % TW, pn, py, pxx) ? 1 : 0;
                 }
@@ -1315,14 +1393,22 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
                 for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            float* pw = s_p + (mh * 64 + 4 * go) * C + nt * 16 + l15o;
+            if (tile_full) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
-                    const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
-                    s_p[ip * C + nt * 16 + l15o] = in ? acc[mi][r] + bias1 : 0.0f;
-                }
+                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * C] = acc[mi][r] + bias1;
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
+                        const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
+                        pw[(mi * 16 + r) * C] = in ? acc[mi][r] + bias1 : 0.0f;
+                    }
+            }
         }
         __syncthreads();
         DP_BWD64_STAMP(1);
@@ -1375,10 +1461,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (!tile_full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = inside((vr0 + r) * TW + vtx, y0 + vr0 + r, x0 + vtx);
+                    if (!in) dp[r] = make_float4(0, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool in = inside((vr0 + r) * TW + vtx, y0 + vr0 + r, x0 + vtx);
-                if (!in) dp[r] = make_float4(0, 0, 0, 0);
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
             }
         }
@@ -1436,43 +1527,64 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
         if (more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
+        // Everything a step needs is requested before the step that consumes it (operands of both k blocks, then the
+        // raw x of the mask): with two waves per SIMD a read -> wait -> use chain per pixel tile is pure LDS latency.
         {
             const int l15o = opaque(l15), go = opaque(g);
             const unsigned char* dbase = s_d + (mh * 64 + l15o) * (C * 2);
             const int sw = l15o & 7;
             const int c = nt * 16 + l15o;
-            const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
-            const float m_lo = s_ci[4 * C + c];
-            float t0 = 0.0f, t1 = 0.0f;
+            f32x4 da[4];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                f32x4 da = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!(abl & 8)) {
+            for (int mi = 0; mi < 4; ++mi) da[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(abl & 8)) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < 2; ++kb) {       // four independent accumulator chains per k block
+                    u32x4 ph[4], pl[4];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
                         const unsigned char* q = dbase + mi * 16 * (C * 2) + (((4 * kb + go) ^ sw) << 4);
-                        const u32x4 ph = *reinterpret_cast<const u32x4*>(q);
-                        const u32x4 pl = *reinterpret_cast<const u32x4*>(q + PLANE);
-                        da = mfma3r(ph, pl, wth[kb], wtl[kb], da);
+                        ph[mi] = *reinterpret_cast<const u32x4*>(q);
+                        pl[mi] = *reinterpret_cast<const u32x4*>(q + PLANE);
                     }
-                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
-                    float v = da[r];
-                    if (bn_in) {
-                        const float xr = s_x[ip * C + c];
-                        const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
-                        v = (in && fmaf(xr - m_mean, m_scale, m_beta) > 0.0f) ? v : 0.0f;      // ReLU mask
-                        t0 += v;
-                        t1 = fmaf(v, bn_center(xr, m_mean, m_lo) * m_inv, t1);
-                    }
-                    s_p[ip * C + c] = v;
+                    for (int mi = 0; mi < 4; ++mi) da[mi] = mfma3r(ph[mi], pl[mi], wth[kb], wtl[kb], da[mi]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // 16 pixels x 4 tiles per lane in fp32 (a handful of terms), then fp64 for the long, heavily
-            // cancelling accumulation over the whole tensor
             if (bn_in) {
+                const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
+                const float m_lo = s_ci[4 * C + c];
+                const float* xrd = s_x + (mh * 64 + 4 * go) * C + c;
+                float* pw = s_p + (mh * 64 + 4 * go) * C + c;
+                float xr[4][4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xr[mi][r] = xrd[(mi * 16 + r) * C];
+                if (!tile_full) {
+                    // a pixel outside the image carries dp = 0, hence da = 0: only the mask of the BN sums is at
+                    // stake, and da = 0 contributes nothing to them either -- but keep x finite and masked
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
+                            if (!inside(ip, y0 + ip / TW, x0 + ip % TW)) da[mi][r] = 0.0f;
+                        }
+                }
+                float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaf(xr[mi][r] - m_mean, m_scale, m_beta) > 0.0f ? da[mi][r] : 0.0f;   // ReLU mask
+                        t0 += v;
+                        t1 = fmaf(v, bn_center(xr[mi][r], m_mean, m_lo) * m_inv, t1);
+                        pw[(mi * 16 + r) * C] = v;
+                    }
+                // 64 pixels per lane in fp32 (a handful of terms), folded over the four lane groups; then fp64 for the
+                // long, heavily cancelling accumulation over the whole tensor
                 t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64);
                 t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
                 if (go == 0) {
@@ -1480,6 +1592,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
                     bs[0] += (double)t0;
                     bs[C] += (double)t1;
                 }
+            } else {
+                float* pw = s_p + (mh * 64 + 4 * go) * C + c;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * C] = da[mi][r];
             }
         }
         __syncthreads();
@@ -1534,14 +1652,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     // ============ flush per-workgroup partial sums ================================================================
 #ifdef DP_BWD_PROF
     if (prof_on && threadIdx.x == 0)
-        for (int q = 0; q < 7; ++q) d.prof[blockIdx.x * 8 + q] = s_prof[q];
+        for (int q = 0; q < 7; ++q) prof_out[blockIdx.x * 8 + q] = s_prof[q];
     const unsigned long long prof_t1 = __builtin_readcyclecounter();
 #endif
     __syncthreads();                                     // the last tile's dx rows have been read
     float* row = d.wgrad_partials + (size_t)blockIdx.x * WROW;
     float* sm = reinterpret_cast<float*>(smem_raw);
     float* s_gw1 = sm;                                   // [KSPLIT][COUT][CIN]
-    float* red = sm + KSPLIT * C * C;                    // [BWD_THREADS][24]
+    float* red = sm + KSPLIT * C * C;                    // [NT][24]
     {
         float* pl = s_gw1 + w1_ks * C * C;
 #pragma unroll
@@ -1556,10 +1674,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
 #pragma unroll
     for (int k = 0; k < 6; ++k) my[k] = gw2[k];
     __syncthreads();
-    for (int i = tid; i < C * C; i += BWD_THREADS) row[i] = s_gw1[i] + s_gw1[C * C + i];
-    constexpr int PG = BWD_THREADS / C4;
+    for (int i = tid; i < C * C; i += NT) {
+        float v = s_gw1[i];
+        if constexpr (KSPLIT == 2) v += s_gw1[C * C + i];
+        row[i] = v;
+    }
+    constexpr int PG = NT / C4;
     auto reduce_pass = [&](int ps, int nslot) {
-        for (int o = tid; o < C * nslot; o += BWD_THREADS) {
+        for (int o = tid; o < C * nslot; o += NT) {
             const int c = o / nslot, k = o - c * nslot;
             const int q = c >> 2, e = c & 3;
             float v = 0.0f;
@@ -1572,35 +1694,37 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd64_kernel(const YunetDP d, 
     };
     reduce_pass(0, 6);
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * C) {
-        const int which = tid / C, c = tid % C;
-        atomic_add_f64(d.in_bn.bstats + tid, s_bst[which * C + c] + s_bst[(2 + which) * C + c]);
+        double v = s_bst[tid];
+        if constexpr (MH == 2) v += s_bst[2 * C + tid];
+        atomic_add_f64(d.in_bn.bstats + tid, v);
     }
     __syncthreads();
     my[0] = gw2[6]; my[1] = gw2[7]; my[2] = gw2[8]; my[3] = gb1; my[4] = gb2;
     __syncthreads();
     reduce_pass(1, 5);
 #ifdef DP_BWD_PROF
-    if (prof_on && threadIdx.x == 0) d.prof[blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - prof_t1;
+    if (prof_on && threadIdx.x == 0) prof_out[blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - prof_t1;
 #endif
 }
 
-template <bool PACKED, bool POOLDY>
+template <int NW, bool PACKED, bool POOLDY>
 int launch_dp_bwd64(const YunetDP* d, hipStream_t stream) {
+    using G = bwd64::Geo<NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd64_kernel<PACKED, POOLDY>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd64::SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd64_kernel<NW, PACKED, POOLDY>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
     PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
     pk.on = PACKED ? 1 : 0;
     if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
-    const int tiles = PACKED ? ((pk.CW + bwd64::TW - 1) / bwd64::TW) * ((pk.CH + bwd64::TH - 1) / bwd64::TH)
-                             : d->N * ((d->W + bwd64::TW - 1) / bwd64::TW) * ((d->H + bwd64::TH - 1) / bwd64::TH);
+    const int tiles = PACKED ? ((pk.CW + G::TW - 1) / G::TW) * ((pk.CH + G::TH - 1) / G::TH)
+                             : d->N * ((d->W + G::TW - 1) / G::TW) * ((d->H + G::TH - 1) / G::TH);
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL((dp_bwd64_kernel<PACKED, POOLDY>), dim3(grid), dim3(BWD_THREADS), bwd64::SMEM, stream, *d, pk);
+    hipLaunchKernelGGL((dp_bwd64_kernel<NW, PACKED, POOLDY>), dim3(grid), dim3(G::NT), G::SMEM, stream, *d, pk);
     return hip_status();
 }
 
@@ -1980,18 +2104,35 @@ inline int ew_grid(long long total) {
 static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
     return cin == 16 && cout == 16 && W >= 64 && H >= 32;
 }
+// Waves per workgroup of dp_bwd64 (the 64 -> 64 units): 8 = one 512-thread workgroup per CU on 8 x 16 tiles,
+// 4 = two independent 256-thread workgroups per CU on 8 x 8 tiles.  Measured (tools/ubench/bwd_ab, N = 256):
+// 80 x 80 0.415 vs 0.429 ms, 40 x 40 0.139 vs 0.126 ms (a 40-wide map fills 8 x 8 tiles exactly, 17 % of every
+// 8 x 16 tile row is padding), packed 20 x 20 / 10 x 10 canvases 0.052 / 0.023 vs 0.055 / 0.028 ms.  So: 8 x 8
+// tiles where the width is a multiple of 8 but not of 16, 8 x 16 otherwise.  YUNET_BWD64_NW=4|8 forces one
+// (A/B runs).  The choice fixes the persistent grid, i.e. the rows of wgrad_partials: read once per process.
+static int bwd64_nw(int N, int H, int W) {
+    static const int forced = [] {
+        const char* e = getenv("YUNET_BWD64_NW");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 4 || forced == 8) return forced;
+    if (dp_pack_geom(N, H, W).on) return 8;
+    return (W % 16 != 0 && W % 8 == 0) ? 4 : 8;
+}
 #ifdef YUNET_ACT_BF16
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout);
 extern "C" int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout);
 extern "C" int yunet_stem_bwd_blocks(int N, int H, int W);
 #else
 extern "C" int yunet_dp_bwd_blocks(int N, int H, int W, int cin, int cout) {
-    const int th = dp_bwd_big_tile(H, W, cin, cout) ? 16 : 8, tw = th * 2;
+    const bool two_per_cu = cin == 64 && cout == 64 && bwd64_nw(N, H, W) == 4;      // dp_bwd64 on 8 x 8 tiles
+    const int th = dp_bwd_big_tile(H, W, cin, cout) ? 16 : 8, tw = two_per_cu ? 8 : th * 2;
     const PackGeom pk = dp_pack_geom(N, H, W);       // small maps: one tile grid over the packed canvas
     const long long tiles = dp_use_pack_bwd(N, H, W, cin, cout)
                                 ? (long long)((pk.CW + tw - 1) / tw) * ((pk.CH + th - 1) / th)
                                   : (long long)N * ((W + tw - 1) / tw) * ((H + th - 1) / th);
-    return (int)(tiles < DP_BWD_MAX_BLOCKS ? tiles : DP_BWD_MAX_BLOCKS);
+    const int cap = two_per_cu ? 2 * DP_BWD_MAX_BLOCKS : DP_BWD_MAX_BLOCKS;
+    return (int)(tiles < cap ? tiles : cap);
 }
 extern "C" int yunet_dp_pool_fusion_ok(int N, int H, int W, int cin, int cout) {
     if ((H & 1) || (W & 1)) return 0;
@@ -2019,7 +2160,7 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
         if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
         if (d->cin == 32) return launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
         if (getenv("YUNET_BWD64_R2")) return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
-        return launch_dp_bwd64<false, true>(d, s);
+        return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, true>(d, s) : launch_dp_bwd64<8, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
@@ -2033,12 +2174,14 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout)) {           // 20x20 / 10x10 levels: packed canvas
         if (d->cout == 64) {
             if (f32mma) return launch_dp_bwd<64, 64, 8, 16, true>(d, s);
-            return r2 ? launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s) : launch_dp_bwd64<true, false>(d, s);
+            if (r2) return launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s);
+            return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, true, false>(d, s) : launch_dp_bwd64<8, true, false>(d, s);
         }
         return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
     }
     if (d->cin == 64 && d->cout == 64 && !f32mma)
-        return r2 ? launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s) : launch_dp_bwd64<false, false>(d, s);
+        return r2 ? launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s)
+                  : bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, false>(d, s) : launch_dp_bwd64<8, false, false>(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

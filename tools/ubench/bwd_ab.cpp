@@ -234,6 +234,8 @@ int main(int argc, char** argv) {
                 CK(hipMalloc(&dprof, (size_t)blocks * 64));
                 CK(hipMemset(dprof, 0, (size_t)blocks * 64));
                 d.prof = dprof;
+                if (getenv("ABL"))     // dp_bwd64 profile builds: ablation mask in the low bits of the aligned pointer
+                    d.prof = (unsigned long long*)((uintptr_t)dprof | ((uintptr_t)atoll(getenv("ABL")) & 63));
             }
             CK(hipMemsetAsync(dbsi, 0, 2 * ci * 8, st));
             int rc = v.bwd(&d, st);
@@ -261,6 +263,15 @@ int main(int argc, char** argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             ms /= reps;
             const double gbs = (double)px * (2 * ci + co) * 4 / (ms * 1e-3) / 1e9;
+            {   // db2 = sum(dz) is zero in exact arithmetic (BN backward): its magnitude against max |dW2| says how
+                // well a variant keeps that cancellation
+                const size_t o2 = (size_t)co * ci + co, o3 = o2 + (size_t)co * 9;
+                double m2 = 0, mw = 0, m1 = 0;
+                for (size_t i = o3; i < (size_t)width; ++i) m2 = fmax(m2, fabs(vw[i]));
+                for (size_t i = o2; i < o3; ++i) mw = fmax(mw, fabs(vw[i]));
+                for (size_t i = (size_t)co * ci; i < o2; ++i) m1 = fmax(m1, fabs(vw[i]));
+                printf("    max|db2| %.3e  max|db1| %.3e  (max|dW2| %.3e)\n", m2, m1, mw);
+            }
             if (vi == 0) {
                 ref_dx = vdx; ref_w = vw; ref_b = hb;
                 printf("%dx%d %d->%d N=%d  %-44s %8.4f ms %7.1f GB/s  (yardstick, %d rows)\n", H, W, ci, co, N,
@@ -274,6 +285,7 @@ int main(int argc, char** argv) {
             }
             if (dprof) {
                 CK(hipMemset(dprof, 0, (size_t)blocks * 64));
+                // d.prof may carry the ablation bits
                 v.bwd(&d, st);
                 CK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hp2((size_t)blocks * 8);
