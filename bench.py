@@ -233,6 +233,12 @@ def op_name(op, L):
         # true = dy is a pooled gradient + argmax bytes (fused max_pool2d backward)
         gemm = ''
         if kind == 'bwd':
+            if d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA') and not os.environ.get('YUNET_BWD64_R2'):
+                # round 3: dp_bwd64_kernel<waves, packed, pooled dy> (csrc/conv_bwd.hip: bwd64_nw) -- 4 waves (8 x 8
+                # tiles, two workgroups per CU) where the width is a multiple of 8 but not of 16, else 8 (8 x 16 tiles)
+                forced = os.environ.get('YUNET_BWD64_NW')
+                nw = int(forced) if forced in ('4', '8') else (4 if (not packed and d.W % 16 != 0 and d.W % 8 == 0) else 8)
+                return f"dp_bwd64_kernel<{nw},{'true' if packed else 'false'},{'true' if d.pool_idx else 'false'}>"
             gemm = ',1' if (d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA')) else ',0'
             gemm += ',true' if d.pool_idx else ',false'
         else:
@@ -250,10 +256,13 @@ def profile_ops(eng, reps=3):
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
     agg = {}
+    eng.lib.yunet_exec_lanes(0)        # single-op timing: everything on the launch stream, FORK / JOIN are no-ops
     for rep in range(reps + 1):
         for arr in (plan.c_fwd_a, plan.c_fwd_b, plan.c_bwd):
             evs = []
             for k in range(len(arr)):
+                if arr[k].opcode in (L.OP_FORK, L.OP_JOIN):
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = eng.lib.yunet_exec(C.cast(C.byref(arr, k * C.sizeof(L.YunetOp)),
@@ -277,6 +286,7 @@ def profile_ops(eng, reps=3):
                     sh['launches'] += 1
                     sh['ms'] += e0.elapsed_time(e1)
                     sh['bytes'] += op_bytes(op, L)
+    eng.lib.yunet_exec_lanes(1)
     for a in agg.values():
         a['launches'] //= reps
         a['ms'] /= reps

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 3
+#define YUNET_ABI_VERSION 4
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -251,8 +251,19 @@ enum {
     YUNET_OP_POOL_FWD, YUNET_OP_POOL_BWD, YUNET_OP_UPADD_FWD, YUNET_OP_UPADD_BWD,
     YUNET_OP_BN_RUNNING, YUNET_OP_BN_PARAM_GRAD, YUNET_OP_REDUCE_PARTIALS,
     YUNET_OP_ASSIGN, YUNET_OP_LOSS_NORM, YUNET_OP_LOSS, YUNET_OP_LOSS_FINALIZE,
-    YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH, YUNET_OP_REDUCE_BATCH
+    YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH, YUNET_OP_REDUCE_BATCH,
+    YUNET_OP_FORK, YUNET_OP_JOIN
 };
+/* Lanes (ABI 4).  The head chains of the pyramid levels (share conv -> fused head, and their backward) are
+ * mutually independent: mmdet/models/dense_heads/yunet_head.py:175-247 walks them in a Python loop, and on the
+ * small levels one launch has ~200 tiles for 256 CUs.  An op with i[YUNET_OP_LANE] = L > 0 is launched on the
+ * executor's side stream L (two side streams, created on first use) instead of `stream`:
+ *   YUNET_OP_FORK  i[0] = bit mask of lanes: those side streams wait for everything enqueued on `stream` so far;
+ *   YUNET_OP_JOIN  i[0] = bit mask of lanes: `stream` waits for everything enqueued on those side streams.
+ * A list must JOIN every lane it FORKed before it ends.  yunet_exec_lanes(0) makes the executor ignore lanes
+ * (everything on `stream`, FORK / JOIN become no-ops): per-launch timing, debugging. */
+#define YUNET_OP_LANE 10
+#define YUNET_MAX_LANES 2
 typedef struct YunetOp {
     int32_t opcode;
     int32_t i[12];
@@ -264,6 +275,7 @@ typedef struct YunetOp {
     YunetLossCfg loss;
 } YunetOp;
 int yunet_exec(const YunetOp* ops /* HOST array */, int n_ops, void* stream);
+int yunet_exec_lanes(int enable);   /* returns the previous setting */
 
 /* ---- the conv stack with bf16 activation storage (YUNET_BF16, see the enum above) ----------------
  * Same arguments as the entry points without the suffix; pointers to ACTIVATION tensors (z, x, pool /

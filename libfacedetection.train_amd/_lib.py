@@ -18,7 +18,8 @@ F32, BF16 = 0, 1
 BOX_EIOU, BOX_DIOU = 0, 1
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
- OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH) = range(1, 20)
+ OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH, OP_FORK, OP_JOIN) = range(1, 22)
+OP_LANE, MAX_LANES = 10, 2          # YunetOp.i[OP_LANE]: side stream of the op (0 = the caller's stream)
 
 
 class YunetBN(C.Structure):
@@ -110,6 +111,7 @@ _SIGNATURES = {
     'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
+    'yunet_exec_lanes': (C.c_int, [C.c_int]),
 }
 for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
            'yunet_upadd_fwd', 'yunet_upadd_bwd'):
@@ -139,7 +141,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 3:
+    if lib.yunet_abi_version() != 4:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

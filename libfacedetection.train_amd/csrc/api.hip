@@ -91,10 +91,57 @@ int yunet_upadd_bwd_bf16(const float*, const YunetBN*, const float*, const Yunet
 
 // Op lists select the activation storage type per op: YunetDP.x_dtype for the ConvDPUnits, i[11] for
 // the stem / pool / upsample-add ops (0 = fp32, 1 = bf16).
-extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
+// ---- lanes: side streams + events of the executor (one set per process; created on first use) -------------------
+static int g_lanes_on = 1;
+static hipStream_t g_side[YUNET_MAX_LANES];
+static hipEvent_t g_fork_ev, g_join_ev[YUNET_MAX_LANES];
+static bool g_lanes_ready = false;
+static int lanes_init() {
+    if (g_lanes_ready) return 0;
+    for (int l = 0; l < YUNET_MAX_LANES; ++l) {
+        if (hipStreamCreateWithFlags(&g_side[l], hipStreamNonBlocking) != hipSuccess) return YUNET_EINVAL;
+        if (hipEventCreateWithFlags(&g_join_ev[l], hipEventDisableTiming) != hipSuccess) return YUNET_EINVAL;
+    }
+    if (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess) return YUNET_EINVAL;
+    g_lanes_ready = true;
+    return 0;
+}
+extern "C" int yunet_exec_lanes(int enable) {
+    const int prev = g_lanes_on;
+    g_lanes_on = enable ? 1 : 0;
+    return prev;
+}
+
+extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
+    unsigned open_lanes = 0;
     for (int k = 0; k < n_ops; ++k) {
         const YunetOp& o = ops[k];
         int rc = 0;
+        void* stream = main_stream;
+        if (o.opcode == YUNET_OP_FORK || o.opcode == YUNET_OP_JOIN) {
+            if (!g_lanes_on) continue;
+            if (lanes_init() != 0) return YUNET_EINVAL * 1000 - k;
+            const unsigned mask = (unsigned)o.i[0] & ((1u << (YUNET_MAX_LANES + 1)) - 2u);
+            if (o.opcode == YUNET_OP_FORK) {
+                if (hipEventRecord(g_fork_ev, (hipStream_t)main_stream) != hipSuccess) return YUNET_EINVAL * 1000 - k;
+                for (int l = 1; l <= YUNET_MAX_LANES; ++l)
+                    if (mask & (1u << l)) hipStreamWaitEvent(g_side[l - 1], g_fork_ev, 0);
+                open_lanes |= mask;
+            } else {
+                for (int l = 1; l <= YUNET_MAX_LANES; ++l)
+                    if (mask & (1u << l)) {
+                        hipEventRecord(g_join_ev[l - 1], g_side[l - 1]);
+                        hipStreamWaitEvent((hipStream_t)main_stream, g_join_ev[l - 1], 0);
+                    }
+                open_lanes &= ~mask;
+            }
+            continue;
+        }
+        const int lane = o.i[YUNET_OP_LANE];
+        if (g_lanes_on && lane > 0) {
+            if (lane > YUNET_MAX_LANES || !(open_lanes & (1u << lane))) return YUNET_EINVAL * 1000 - k;   // not forked
+            stream = (void*)g_side[lane - 1];
+        }
         switch (o.opcode) {
             case YUNET_OP_STEM_FWD:
                 rc = (o.i[11] == YUNET_BF16 ? yunet_stem_fwd_bf16 : yunet_stem_fwd)((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
@@ -181,6 +228,14 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* stream) {
                 return YUNET_EOPCODE;
         }
         if (rc != 0) return rc < 0 ? rc * 1000 - k : -(rc * 1000 + k);
+    }
+    if (open_lanes) {      // a list must not end with work pending on a side stream: join defensively, report
+        for (int l = 1; l <= YUNET_MAX_LANES; ++l)
+            if (open_lanes & (1u << l)) {
+                hipEventRecord(g_join_ev[l - 1], g_side[l - 1]);
+                hipStreamWaitEvent((hipStream_t)main_stream, g_join_ev[l - 1], 0);
+            }
+        return YUNET_EINVAL * 1000 - n_ops;
     }
     return 0;
 }

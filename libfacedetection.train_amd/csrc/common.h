@@ -141,6 +141,28 @@ __device__ __forceinline__ BNBwd bn_bwd_coef(const YunetBN& bn, int C, int c) {
     return k;
 }
 
+// The same backward as  dz = A dy + B z + D:  A = k1, B = -k1 c2 invstd rounded to fp32, and
+// D = -A c1 - B mean evaluated in fp64 WITH the rounded B and carried as a (hi, lo) pair.  The rounding of B
+// then scales the centred term (z - mean) by 1 + 6e-8 instead of shifting every dz of the channel by
+// 6e-8 |B mean| -- the systematic offset that breaks sum(dz) = 0 (see bn_center below).  Two FMAs and an add
+// per element; measured on the 80 x 80 backward harness, |sum dz| is 30x smaller than with the nine-operation
+// form (tools/ubench/bwd_ab: max |db2| 4.1e-4 vs 1.2e-2).
+struct BNFold {
+    float a, b, dh, dl;
+};
+__device__ __forceinline__ BNFold bn_fold(const BNBwd& k) {
+    BNFold f;
+    f.a = k.k1;
+    f.b = (float)(-(double)k.k1 * (double)k.c2 * (double)k.invstd);
+    const double D = -(double)f.a * ((double)k.c1 + (double)k.c1_lo) - (double)f.b * ((double)k.mean + (double)k.mean_lo);
+    f.dh = (float)D;
+    f.dl = (float)(D - (double)f.dh);
+    return f;
+}
+__device__ __forceinline__ float bn_dz_folded(float dy, float z, float a, float b, float dh, float dl) {
+    return fmaf(a, dy, fmaf(b, z, dh)) + dl;
+}
+
 // x - mean with the mean carried as a (hi, lo) float pair.  A plain float mean is off by up to
 // 6e-8*|mean| for EVERY element of the channel, which makes sum(xhat) and sum(dz) of the BN
 // backward non-zero by cnt*6e-8*|mean|/sigma; multiplied by mean(p) (depthwise weight gradient)

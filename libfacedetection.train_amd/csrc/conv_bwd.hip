@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     // the parameter/coefficient block sits after the (possibly larger) reduction work area
     float* s_w1 = reinterpret_cast<float*>(smem_raw + G::WORKB);   // [COUT][WS]  (GEMM 1: bf16 planes hi | lo [COUT][WSB], then b1[COUT])
     float* s_w2 = s_w1 + G::W1_F;                                  // [9][COUT]
-    float* s_co = s_w2 + 9 * COUT;                                 // mean|invstd|k1|c1|c2|mean_lo|c1_lo
+    float* s_co = s_w2 + 9 * COUT;                                 // folded BN backward of the unit's own BN: A|B|Dh|Dl (+3 spare rows)
     float* s_ci = s_co + 7 * COUT;                                 // mean|scale|beta|invstd|mean_lo
     float* s_w1t = s_ci + 5 * CIN;                                 // [CIN][WST] (B operand of the da GEMM; GEMM 1: planes hi | lo [CIN][WSTB])
     double* s_bst = reinterpret_cast<double*>(s_w1t + G::W1T_F);   // [2][CIN] producer's BN-backward sums
@@ -343,16 +343,13 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     }
     for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
     for (int c = tid; c < COUT; c += BWD_THREADS) {
+        // dz = k1 * (dy - c1 - xhat * c2) folded into dz = A dy + B z + D (see bn_fold in common.h)
         if (bn_out) {
-            const BNBwd k = bn_bwd_coef(d.out_bn, COUT, c);
-            s_co[c] = k.mean; s_co[COUT + c] = k.invstd; s_co[2 * COUT + c] = k.k1;
-            s_co[3 * COUT + c] = k.c1; s_co[4 * COUT + c] = k.c2;
-            s_co[5 * COUT + c] = k.mean_lo; s_co[6 * COUT + c] = k.c1_lo;
+            const BNFold f = bn_fold(bn_bwd_coef(d.out_bn, COUT, c));
+            s_co[c] = f.a; s_co[COUT + c] = f.b; s_co[2 * COUT + c] = f.dh; s_co[3 * COUT + c] = f.dl;
         } else {
-            s_co[c] = 0.f; s_co[COUT + c] = 0.f;
-            s_co[2 * COUT + c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
-            s_co[3 * COUT + c] = 0.f; s_co[4 * COUT + c] = 0.f;
-            s_co[5 * COUT + c] = 0.f; s_co[6 * COUT + c] = 0.f;
+            s_co[c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
+            s_co[COUT + c] = 0.f; s_co[2 * COUT + c] = 0.f; s_co[3 * COUT + c] = 0.f;
         }
     }
     for (int c = tid; c < CIN; c += BWD_THREADS) {
@@ -407,13 +404,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         {
             const int tid = G::LAUNDER ? opaque((int)threadIdx.x) : (int)threadIdx.x;
             const int och4 = tid % G::C4O, ich4 = tid % G::C4I;
-            const float4 o_mean = *reinterpret_cast<float4*>(s_co + och4 * 4);
-            const float4 o_inv = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
-            const float4 o_k1 = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
-            const float4 o_c1 = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
-            const float4 o_c2 = *reinterpret_cast<float4*>(s_co + 4 * COUT + och4 * 4);
-            const float4 o_ml = *reinterpret_cast<float4*>(s_co + 5 * COUT + och4 * 4);
-            const float4 o_cl = *reinterpret_cast<float4*>(s_co + 6 * COUT + och4 * 4);
+            const float4 o_a = *reinterpret_cast<float4*>(s_co + och4 * 4);
+            const float4 o_b = *reinterpret_cast<float4*>(s_co + COUT + och4 * 4);
+            const float4 o_dh = *reinterpret_cast<float4*>(s_co + 2 * COUT + och4 * 4);
+            const float4 o_dl = *reinterpret_cast<float4*>(s_co + 3 * COUT + och4 * 4);
             const int hp0 = tid / G::C4O;
 #pragma unroll
             for (int i = 0; i < G::NDZ; ++i) {
@@ -429,18 +423,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                         dy.z = ((id >> 16) & 0xffu) == pos ? dy.z : 0.0f;
                         dy.w = (id >> 24) == pos ? dy.w : 0.0f;
                     }
+                    // zero padding of dz: a slot outside the image loaded dy = z = 0, which the BN backward
+                    // would turn into D
+                    const bool ok = (okmask >> i) & 1u;
                     float4 v;
-                    if (bn_out) {
-                        // zero padding of dz: a slot outside the image loaded dy = z = 0, which the
-                        // BN backward would turn into a non-zero value
-                        const bool ok = (okmask >> i) & 1u;
-                        v.x = ok ? bn_dz(dy.x, z.x, o_mean.x, o_ml.x, o_inv.x, o_k1.x, o_c1.x, o_cl.x, o_c2.x) : 0.0f;
-                        v.y = ok ? bn_dz(dy.y, z.y, o_mean.y, o_ml.y, o_inv.y, o_k1.y, o_c1.y, o_cl.y, o_c2.y) : 0.0f;
-                        v.z = ok ? bn_dz(dy.z, z.z, o_mean.z, o_ml.z, o_inv.z, o_k1.z, o_c1.z, o_cl.z, o_c2.z) : 0.0f;
-                        v.w = ok ? bn_dz(dy.w, z.w, o_mean.w, o_ml.w, o_inv.w, o_k1.w, o_c1.w, o_cl.w, o_c2.w) : 0.0f;
-                    } else {
-                        v = make_float4(dy.x * o_k1.x, dy.y * o_k1.y, dy.z * o_k1.z, dy.w * o_k1.w);
-                    }
+                    v.x = ok ? fmaf(o_a.x, dy.x, fmaf(o_b.x, z.x, o_dh.x)) + o_dl.x : 0.0f;
+                    v.y = ok ? fmaf(o_a.y, dy.y, fmaf(o_b.y, z.y, o_dh.y)) + o_dl.y : 0.0f;
+                    v.z = ok ? fmaf(o_a.z, dy.z, fmaf(o_b.z, z.z, o_dh.z)) + o_dl.z : 0.0f;
+                    v.w = ok ? fmaf(o_a.w, dy.w, fmaf(o_b.w, z.w, o_dh.w)) + o_dl.w : 0.0f;
                     *reinterpret_cast<float4*>(s_dz + hp * G::LSO + och4 * 4) = v;
                 }
             }
@@ -1244,18 +1234,11 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     for (int c = tid; c < C; c += NT) s_b1[c] = d.b_pw[c];
     for (int i = tid; i < C * 9; i += NT) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
     for (int c = tid; c < C; c += NT) {
-        // dz = k1 * (dy - c1 - xhat * c2), xhat = (z - mean) * invstd, folded into  dz = A dy + B z + D  with
-        // A = k1, B = -k1 c2 invstd (rounded to fp32) and D = -A c1 - B mean evaluated in fp64 WITH the rounded
-        // B and carried as a (hi, lo) pair: the rounding of B then scales the centred term (z - mean) by 1 + 6e-8
-        // instead of shifting every dz of the channel by 6e-8 |B mean| -- the systematic offset that would break
-        // sum(dz) = 0 (bn_center in common.h) -- and the nine operations per element become two FMAs and an add
+        // dz = k1 * (dy - c1 - xhat * c2) folded into dz = A dy + B z + D (bn_fold in common.h): two FMAs and an
+        // add per element instead of nine operations
         if (bn_out) {
-            const BNBwd k = bn_bwd_coef(d.out_bn, C, c);
-            const float A = k.k1;
-            const float B = (float)(-(double)k.k1 * (double)k.c2 * (double)k.invstd);
-            const double D = -(double)A * ((double)k.c1 + (double)k.c1_lo) - (double)B * ((double)k.mean + (double)k.mean_lo);
-            const float Dh = (float)D;
-            s_co[c] = A; s_co[C + c] = B; s_co[2 * C + c] = Dh; s_co[3 * C + c] = (float)(D - (double)Dh);
+            const BNFold f = bn_fold(bn_bwd_coef(d.out_bn, C, c));
+            s_co[c] = f.a; s_co[C + c] = f.b; s_co[2 * C + c] = f.dh; s_co[3 * C + c] = f.dl;
         } else {
             s_co[c] = d.dy_scale ? d.dy_scale[c] : 1.0f;
             s_co[C + c] = 0.f; s_co[2 * C + c] = 0.f; s_co[3 * C + c] = 0.f;
@@ -1747,22 +1730,20 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float s_all[ALL_F];
     float* s_patch = s_all;
     float* s_dzt = s_all + PATCH_F;
-    __shared__ float s_k[7][16];
+    __shared__ float s_k[4][16];
     const int tid = threadIdx.x;
     const int Ho = H / 2, Wo = W / 2;
     if (tid < 16) {
-        const BNBwd k = bn_bwd_coef(bn, 16, tid);
-        s_k[0][tid] = k.mean; s_k[1][tid] = k.invstd; s_k[2][tid] = k.k1;
-        s_k[3][tid] = k.c1; s_k[4][tid] = k.c2; s_k[5][tid] = k.mean_lo; s_k[6][tid] = k.c1_lo;
+        const BNFold f = bn_fold(bn_bwd_coef(bn, 16, tid));     // dz = A dy + B z + D (common.h)
+        s_k[0][tid] = f.a; s_k[1][tid] = f.b; s_k[2][tid] = f.dh; s_k[3][tid] = f.dl;
     }
     __syncthreads();
     const int lc4 = tid & 3;  // channel quad in the dz load phase
-    float km[4], ki[4], k1[4], c1[4], c2[4], kml[4], c1l[4];
+    float fa[4], fb[4], fdh[4], fdl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        km[i] = s_k[0][lc4 * 4 + i]; ki[i] = s_k[1][lc4 * 4 + i]; k1[i] = s_k[2][lc4 * 4 + i];
-        c1[i] = s_k[3][lc4 * 4 + i]; c2[i] = s_k[4][lc4 * 4 + i];
-        kml[i] = s_k[5][lc4 * 4 + i]; c1l[i] = s_k[6][lc4 * 4 + i];
+        fa[i] = s_k[0][lc4 * 4 + i]; fb[i] = s_k[1][lc4 * 4 + i];
+        fdh[i] = s_k[2][lc4 * 4 + i]; fdl[i] = s_k[3][lc4 * 4 + i];
     }
     // role: 4 output-channel quads x 4 tap groups of 7; 16 pixel slices of 16 pixels
     const int role = tid & 15, slice = tid >> 4;
@@ -1826,10 +1807,10 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                 const size_t off = (((size_t)n * Ho + oy) * Wo + ox) * 16 + lc4 * 4;
                 const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
                 const float4 z4 = act_ld4(z + off);
-                v.x = bn_dz(g4.x, z4.x, km[0], kml[0], ki[0], k1[0], c1[0], c1l[0], c2[0]);
-                v.y = bn_dz(g4.y, z4.y, km[1], kml[1], ki[1], k1[1], c1[1], c1l[1], c2[1]);
-                v.z = bn_dz(g4.z, z4.z, km[2], kml[2], ki[2], k1[2], c1[2], c1l[2], c2[2]);
-                v.w = bn_dz(g4.w, z4.w, km[3], kml[3], ki[3], k1[3], c1[3], c1l[3], c2[3]);
+                v.x = bn_dz_folded(g4.x, z4.x, fa[0], fb[0], fdh[0], fdl[0]);
+                v.y = bn_dz_folded(g4.y, z4.y, fa[1], fb[1], fdh[1], fdl[1]);
+                v.z = bn_dz_folded(g4.z, z4.z, fa[2], fb[2], fdh[2], fdl[2]);
+                v.w = bn_dz_folded(g4.w, z4.w, fa[3], fb[3], fdh[3], fdl[3]);
             }
             *reinterpret_cast<float4*>(s_dzt + pix * DZS + lc4 * 4) = v;
         }

@@ -225,7 +225,9 @@ class Plan:
         self.producer = {}      # id(tensor) -> (cin, cout) of the ConvDPUnit that wrote it
         self.fwd_op_of = {}     # id(tensor) -> its OP_DP_FWD record
         self.fwd_a, self.fwd_b, self.bwd = [], [], []
-        self.bwd_nodes = []     # closures generating backward ops (appended in fwd order)
+        self.bwd_nodes = []     # (lane, closure generating backward ops, lane to JOIN first | None), in fwd order
+        self._lane = 0          # executor lane of the ops being appended (0 = the caller's stream)
+        self._join_before = None
         self.tensors = {}       # unit name -> (input _T, output _T): introspection / debugging
         f32 = dict(device=dev, dtype=torch.float32)
 
@@ -273,19 +275,50 @@ class Plan:
             if i in arch['downsample_idx']:
                 # the pool is the stage output's only consumer unless the stage is also tapped by the neck
                 cur = self._pool(cur, sole_consumer=i not in arch['out_idx'])
+        # The head chain of a pyramid level (share convs -> fused head) depends on that level's lateral conv only,
+        # and the levels are mutually independent (yunet_head.py:175-247 loops over them): the chains of the coarser
+        # levels CAN run on executor lanes (side streams) next to the rest of the top-down pathway; level 0 stays on
+        # the caller's stream.  Off by default (YUNET_LANES=1 turns it on): measured on YuNet_n 320 x 320 bs 256 the
+        # step is 5.375 ms with lanes vs 5.340 ms without -- a packed 20 x 20 launch already has 882 tiles for the
+        # 256 CUs, only the 10 x 10 launches (242 tiles, 23 us each) leave CUs idle, and the backward kernel's
+        # 149 KB of LDS admits one workgroup per CU, so concurrent launches queue instead of sharing CUs.
         feats = list(taps)
-        for i in range(len(feats) - 1, 0, -1):
-            feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
-            feats[i - 1] = self._upadd(feats[i - 1], feats[i])
-        feats[0] = self._dp(feats[0], 'neck.lateral_convs.0')
-        outs = [feats[i] for i in arch['neck_out_idx']]
-        assert [(t.h, t.w) for t in outs] == self.sizes, 'feature sizes vs strides'
-        base = 0
-        for l, f in enumerate(outs):
+        level_of = {i: l for l, i in enumerate(arch['neck_out_idx'])}
+        bases, b0 = [], 0
+        for hh, ww in self.sizes:
+            bases.append(b0)
+            b0 += hh * ww
+        lanes_ok = bool(os.environ.get('YUNET_LANES')) or bool(getattr(eng, 'use_lanes', False))
+        self.lanes_used = 0
+
+        def head_chain(i):
+            l = level_of.get(i)
+            if l is None:
+                return
+            f = feats[i]
+            assert (f.h, f.w) == self.sizes[l], 'feature sizes vs strides'
+            lane = l if (lanes_ok and 0 < l <= L.MAX_LANES) else 0
+            if lane:
+                self.fwd_a.append(self._op(L.OP_FORK, i=[1 << lane]))
+                self.lanes_used |= 1 << lane
+                f.head_lane = lane
+            self._lane = lane
             for j in range(arch['shared_stacked_convs']):
                 f = self._dp(f, f'bbox_head.multi_level_share_convs.{l}.{j}')
-            self._head(f, l, base)
-            base += f.h * f.w
+            self._head(f, l, bases[l])
+            self._lane = 0
+        for i in range(len(feats) - 1, 0, -1):
+            feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
+            head_chain(i)
+            # the backward of this merge ACCUMULATES into feats[i]'s gradient after the level's head chain (on its
+            # lane) has written it: the executor joins that lane first
+            self._join_before = getattr(feats[i], 'head_lane', None)
+            feats[i - 1] = self._upadd(feats[i - 1], feats[i])
+            self._join_before = None
+        feats[0] = self._dp(feats[0], 'neck.lateral_convs.0')
+        head_chain(0)
+        if self.lanes_used:
+            self.fwd_a.append(self._op(L.OP_JOIN, i=[self.lanes_used]))
 
         # ---- loss step
         self.gt_boxes = torch.zeros(n, gmax, 4, **f32)
@@ -345,12 +378,25 @@ class Plan:
                               fp.running_mean.data_ptr(), fp.running_var.data_ptr(), None],
             i=[len(rows_f), 0], f=[BN_MOMENTUM]))
 
-        # ---- backward: reverse of the forward nodes
+        # ---- backward: reverse of the forward nodes; the head chains of the lanes first (their gradients exist
+        # from the start), each on its lane, then the caller's stream walks the rest and joins a lane right before
+        # the first op that accumulates into a gradient that lane wrote
         self.reduce_jobs = []   # (partials ptr, grad ptr, rows, width, accumulate) of every unit
         marks = []              # after each backward node: (#ops, #reduce jobs)
-        for node in reversed(self.bwd_nodes):
+        if self.lanes_used:
+            self.bwd.append(self._op(L.OP_FORK, i=[self.lanes_used]))
+        joined = 0
+        order = [nd for nd in reversed(self.bwd_nodes) if nd[0] > 0] + [nd for nd in reversed(self.bwd_nodes) if nd[0] == 0]
+        for lane, node, join in order:
+            if join and not (joined >> join) & 1:
+                self.bwd.append(self._op(L.OP_JOIN, i=[1 << join]))
+                joined |= 1 << join
+            self._lane = lane
             node()
+            self._lane = 0
             marks.append((len(self.bwd), len(self.reduce_jobs)))
+        if self.lanes_used & ~joined:
+            self.bwd.append(self._op(L.OP_JOIN, i=[self.lanes_used & ~joined]))
         kernels_bwd = list(self.bwd)
         # all weight-gradient partial reductions in ONE launch (table lives on the device)
         self.reduce_table, chunk = K.reduce_job_table(self.reduce_jobs, dev)
@@ -429,6 +475,7 @@ class Plan:
     def _op(self, opcode, p=(), i=(), f=()):
         op = L.YunetOp()
         op.opcode = opcode
+        op.i[L.OP_LANE] = self._lane if opcode not in (L.OP_FORK, L.OP_JOIN) else 0
         op.i[11] = self.act_flag          # stem / pool / upsample-add ops: activation storage type
         for k, v in enumerate(p):
             op.p[k] = v
@@ -493,7 +540,7 @@ class Plan:
             self.bwd.append(op)
             self.img_ptr_ops.append(('bwd', len(self.bwd) - 1))
             self.reduce_jobs.append((part.data_ptr(), gptr, blocks, width, 0))
-        self.bwd_nodes.append(bwd)
+        self.bwd_nodes.append((self._lane, bwd, self._join_before))
 
     def _dp_desc(self, x, name, z, z_img_stride=None):
         lay, fp = self.eng.layout, self.eng.params
@@ -566,7 +613,7 @@ class Plan:
             op.dp = d2
             self.bwd.append(op)
             self.reduce_jobs.append((part.data_ptr(), gptr, blocks, width, 0))
-        self.bwd_nodes.append(bwd)
+        self.bwd_nodes.append((self._lane, bwd, self._join_before))
 
     def _pool(self, x, sole_consumer=False):
         # Fused pooling: when the pool is the only consumer of x and the producing unit has the
@@ -597,7 +644,7 @@ class Plan:
                           i=[x.n, x.h, x.w, x.c, acc])
             op.bn[0] = self._bn_struct(x.bn, cnt)
             self.bwd.append(op)
-        self.bwd_nodes.append(bwd)
+        self.bwd_nodes.append((self._lane, bwd, self._join_before))
         return out
 
     def _upadd(self, a, b):
@@ -619,7 +666,7 @@ class Plan:
             op.bn[0] = self._bn_struct(a.bn, a.n * a.h * a.w)
             op.bn[1] = self._bn_struct(b.bn, b.n * b.h * b.w)
             self.bwd.append(op)
-        self.bwd_nodes.append(bwd)
+        self.bwd_nodes.append((self._lane, bwd, self._join_before))
         return out
 
     def set_img(self, img):
@@ -649,6 +696,7 @@ class YuNetEngine:
         self.plans = {}
         self.plan = None
         self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
+        self.use_lanes = False          # head chains of the coarser levels on executor side streams (Plan.__init__)
         self.precision = 'fp32'         # 'fp32' | 'bf16' (activation storage + forward matrix instruction)
         self.lib = L.load()
         self._host_idx = {}

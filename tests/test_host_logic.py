@@ -88,10 +88,11 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
     import yunet_amd.engine as E
     for kind, h in (('n', 320), ('s', 160)):
         eng = E.YuNetEngine(O.yunet_arch(kind), 'cpu')
+        eng.use_lanes = True            # executor lanes for the head chains (off by default: no measured gain)
         plan = eng.get_plan(2, h, h, 3)
         assert plan.P == sum((h // s) ** 2 for s in (8, 16, 32))
         ops = plan.fwd_a + plan.fwd_b + plan.bwd
-        assert all(1 <= op.opcode <= L.OP_REDUCE_BATCH for op in ops)
+        assert all(1 <= op.opcode <= L.OP_JOIN for op in ops)
         # every unit's weight-gradient partials are reduced by the one batched op at the end
         red = [op for op in plan.bwd if op.opcode == L.OP_REDUCE_BATCH]
         assert len(red) == 1 and red[0].i[0] == len(plan.reduce_jobs)
@@ -115,6 +116,38 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
         assert len(multi) == 4                      # two backbone taps + two lateral outputs
         for w in writers.values():
             assert w[0] == 0 and all(a == 1 for a in w[1:])
+        # executor lanes: the head chains of levels 1 and 2 run on side streams.  Every list forks a lane before
+        # its first op on it and joins it before the list ends; in backward a lane is joined BEFORE the
+        # upsample-add that accumulates into the gradient that lane's chain wrote first (accumulate flag 1).
+        for ops_l in (plan.fwd_a, plan.bwd, plan.fwd_eval):
+            open_l = 0
+            for op in ops_l:
+                if op.opcode == L.OP_FORK:
+                    open_l |= op.i[0]
+                elif op.opcode == L.OP_JOIN:
+                    assert op.i[0] & open_l == op.i[0]
+                    open_l &= ~op.i[0]
+                else:
+                    lane = op.i[L.OP_LANE]
+                    assert 0 <= lane <= L.MAX_LANES and (lane == 0 or (open_l >> lane) & 1), 'op on a lane that is not forked'
+            assert open_l == 0, 'a list ends with a lane still open'
+        assert plan.lanes_used == 0b110
+        lane_ops = [op for op in plan.fwd_a if op.i[L.OP_LANE] > 0]
+        assert len(lane_ops) == 2 * (2 if kind == 'n' else 1) and all(op.opcode == L.OP_DP_FWD for op in lane_ops)
+        wrote = {}                      # gradient buffer -> lane whose backward wrote it first
+        open_l = 0
+        for op in plan.bwd:
+            if op.opcode == L.OP_FORK:
+                open_l |= op.i[0]
+            elif op.opcode == L.OP_JOIN:
+                open_l &= ~op.i[0]
+            elif op.opcode == L.OP_DP_BWD and op.i[L.OP_LANE] > 0:
+                wrote[op.dp.dx] = op.i[L.OP_LANE]
+            elif op.opcode == L.OP_UPADD_BWD:
+                for ptr, acc in ((op.p[3], op.i[4]), (op.p[4], op.i[5])):
+                    if ptr in wrote:
+                        assert acc == 1 and not (open_l >> wrote[ptr]) & 1, 'accumulating into a gradient whose lane is not joined'
+        assert len([1 for op in plan.bwd if op.opcode == L.OP_UPADD_BWD]) == 2
     with pytest.raises(ValueError, match='multiples of 32'):
         E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(1, 100, 100, 1)
 
