@@ -241,6 +241,12 @@ def op_name(op, L):
                 return f"dp_bwd64_kernel<{nw},{'true' if packed else 'false'},{'true' if d.pool_idx else 'false'}>"
             gemm = ',1' if (d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA')) else ',0'
             gemm += ',true' if d.pool_idx else ',false'
+            # last argument: the whole-tile instance (map = exact multiple of the tile, no validity tests)
+            th, tw = (16, 32) if big else (8, 16)
+            full = (not packed and d.H % th == 0 and d.W % tw == 0 and
+                    ((d.cin, d.cout) in ((16, 16), (16, 32), (16, 64), (32, 32)) if not d.pool_idx else d.cin in (16, 32))
+                    and (big or (d.cin, d.cout) != (16, 16)))
+            gemm += ',true' if full else ',false'
         else:
             gemm = ',true' if d.pool_out else ',false'      # forward: fused pooling outputs
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"

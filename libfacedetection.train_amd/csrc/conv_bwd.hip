@@ -155,7 +155,10 @@ __device__ __forceinline__ f32x4 mfma3(const Split8& a, const u32x4 bh, const u3
     return c;
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED, int GEMM = 0, bool POOLDY = false>
+// FULL: the map is an exact multiple of the tile (H % TH == 0, W % TW == 0: the 160 x 160 and 80 x 80 levels), so
+// every interior tile pixel is a real pixel and the per-element validity tests -- hundreds of integer
+// instructions per tile -- compile away.  The launch picks the instance.
+template <int CIN, int COUT, int TH, int TW, bool PACKED, int GEMM = 0, bool POOLDY = false, bool FULL = false>
 __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, const PackGeom pk) {
     using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -200,8 +203,10 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     // inside(ip, Y, X): is interior tile pixel ip = (Y, X) a real pixel?  Packed tiles look it up in
     // a per-tile byte map written during the stage (one canvas -> image mapping per pixel and tile
     // instead of one per use).
+    static_assert(!(FULL && PACKED), "FULL: unpacked maps only");
     auto inside = [&](int ip, int y, int x) {
-        if constexpr (PACKED) return s_in[ip] != 0;
+        if constexpr (FULL) return true;
+        else if constexpr (PACKED) return s_in[ip] != 0;
         else return y < H && x < W;
     };
 
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 off = pk_locate(pk, y, x, pn, py, px)
                           ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * ACT_B : xrange;
             } else {
-                off = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * ACT_B : xbytes;
+                off = (FULL || (y < H && x < W)) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * ACT_B : xbytes;
             }
             px[i] = act_bufld4(r_x, off);
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                     off[i] = pk_locate(pk, y, x, pn, py, px)
                                  ? (unsigned)(pn * d.x_img_stride + (py * W + px) * CIN + ich4 * 4) * 4u : xrange;
                 } else {
-                    off[i] = (y < H && x < W) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : dxbytes;
+                    off[i] = (FULL || (y < H && x < W)) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * 4u : dxbytes;
                 }
             }
             // two separate paths: the plain store must not wait on the vector-memory counter (the next
@@ -935,12 +940,15 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #endif
 }
 
-template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0, bool POOLDY = false>
+template <int CIN, int COUT, int TH, int TW, bool PACKED = false, int GEMM = 0, bool POOLDY = false, bool FULL = false>
 int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     using G = BwdGeom<CIN, COUT, TH, TW, GEMM>;
+    if constexpr (FULL) {
+        if (d->H % TH != 0 || d->W % TW != 0) return YUNET_EINVAL;
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
@@ -952,7 +960,7 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
-    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
+    hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY, FULL>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
                        stream, *d, pk);
     return hip_status();
 }
@@ -2138,15 +2146,19 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (d->pool_idx) {
         // dy is the pooled gradient + argmax bytes (max_pool2d backward while staging)
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;
-        if (d->cin == 16) return launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
-        if (d->cin == 32) return launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
+        const bool full816 = d->H % 8 == 0 && d->W % 16 == 0, full1632 = d->H % 16 == 0 && d->W % 32 == 0;
+        if (d->cin == 16) return full1632 ? launch_dp_bwd<16, 16, 16, 32, false, 0, true, true>(d, s)
+                                          : launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
+        if (d->cin == 32) return full816 ? launch_dp_bwd<32, 64, 8, 16, false, 0, true, true>(d, s)
+                                         : launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
         if (getenv("YUNET_BWD64_R2")) return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
         return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, true>(d, s) : launch_dp_bwd64<8, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
     if (d->cin == ci && d->cout == co) return launch_dp_bwd<ci, co, 8, 16>(d, s);
-    if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))
-        return launch_dp_bwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
+    if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))    // 160x160 / 80x80 levels: bigger tile
+        return (d->H % 16 == 0 && d->W % 32 == 0) ? launch_dp_bwd<16, 16, 16, 32, false, 0, false, true>(d, s)
+                                                  : launch_dp_bwd<16, 16, 16, 32>(d, s);
     // 64 -> 64 units: split-bf16 GEMMs (gradients only); YUNET_BWD_FP32MMA=1 keeps the exact-fp32
     // matrix instruction (A/B measurements, tools/kbench.py)
     const bool f32mma = getenv("YUNET_BWD_FP32MMA") != nullptr;
@@ -2163,6 +2175,11 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (d->cin == 64 && d->cout == 64 && !f32mma)
         return r2 ? launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s)
                   : bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, false>(d, s) : launch_dp_bwd64<8, false, false>(d, s);
+    if (d->H % 8 == 0 && d->W % 16 == 0) {       // whole-tile maps of the 16-channel stages (80 x 80 in the shipped nets)
+        if (d->cin == 16 && d->cout == 64) return launch_dp_bwd<16, 64, 8, 16, false, 0, false, true>(d, s);
+        if (d->cin == 16 && d->cout == 32) return launch_dp_bwd<16, 32, 8, 16, false, 0, false, true>(d, s);
+        if (d->cin == 32 && d->cout == 32) return launch_dp_bwd<32, 32, 8, 16, false, 0, false, true>(d, s);
+    }
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)
