@@ -329,11 +329,13 @@ def effective_cores():
     return cores
 
 
-def ref_vs_port():
-    """Measured ratio reference-under-stub / port on the build box (profiles/r*_cpu_ref_vs_port.json,
-    written by tools/cpu_ref_vs_port.py where /root/reference exists); None if never measured."""
+def ref_vs_port(bs=None):
+    """Measured ratio reference-under-stub / port on the build box (profiles/r*_cpu_ref_vs_port[_bsNN].json,
+    written by tools/cpu_ref_vs_port.py where /root/reference exists) -- the file measured at the batch size
+    the baseline reports if there is one, else the newest; None if never measured."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_ref_vs_port.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_cpu_ref_vs_port_bs{bs}.json'))) if bs else []
+    files = files or sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_ref_vs_port*.json')))
     if not files:
         return None
     try:
@@ -387,10 +389,10 @@ def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
                     sample=what + ', eager PyTorch-ROCm ops on cuda:0 (un-accelerated GPU row)')
     res = dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
                sample=what + f', {cores} threads')
-    rp = ref_vs_port()
+    rp = ref_vs_port(bs)
     if rp:
         res['reference_over_port'] = rp.get('ratio')
-        res['sample'] += (f"; on the build box ({rp.get('cores')} cores) the reference's own files under the "
+        res['sample'] += (f"; on the build box ({rp.get('cores')} cores, {rp.get('workload')}) the reference's own files under the "
                           f"mmcv stub ran {rp.get('reference_img_s')} img/s vs this port {rp.get('port_img_s')} "
                           f"img/s (ratio {rp.get('ratio')}, tools/cpu_ref_vs_port.py)")
     return res
@@ -488,6 +490,8 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    if world > 1:
+        model.engine.comm_timing = True      # events around the collectives: exposed / overlapped ms per step
     bar = dict(device_ids=[local]) if world > 1 and dist.get_backend() == 'nccl' else {}
     if world > 1:
         dist.barrier(**bar)
@@ -500,6 +504,7 @@ def main():
         dist.barrier(**bar)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm = model.engine.comm_report(a.steps) if world > 1 else None
     per_rank = [dt]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -534,6 +539,9 @@ def main():
             'per_rank_images_per_sec': [round(a.batch * a.steps / t, 1) for t in per_rank],
             'dist': {'backend': dist.get_backend() if world > 1 else None, 'world_size': world,
                      'collectives_per_step': 0 if world == 1 else 3,
+                     # rank 0's events around the collectives (engine.comm_report): what the launch stream spends in /
+                     # behind communication per step, and the bucket that runs under the early-stage backward kernels
+                     'comm_ms_per_step': comm,
                      'note': 'num_pos (4 B) | gradient bucket A on a side stream under the backward '
                              'kernels of the early stages | bucket B + the 5 logged scalars'},
         }

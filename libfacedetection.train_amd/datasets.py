@@ -129,6 +129,26 @@ class RetinaFaceDataset:
     def load_image(self, idx):
         return imread_bgr(os.path.join(self.img_prefix, self.data_infos[idx]['filename']))
 
+    def evaluate(self, results, metric='mAP', logger=None, iou_thr=0.5, **_):
+        """CustomDataset.evaluate (mmdet/datasets/custom.py:310-367) for the metric the shipped configs ask
+        for (`evaluation = dict(interval=..., metric='mAP')`): AP of the face class at each IoU threshold."""
+        from collections import OrderedDict
+        from .evaluation import eval_map_single_class
+        if not isinstance(metric, str):
+            assert len(metric) == 1
+            metric = metric[0]
+        if metric != 'mAP':
+            raise KeyError(f'metric {metric} is not supported')
+        anns = [self.get_ann_info(i) for i in range(len(results))]
+        thrs = [iou_thr] if isinstance(iou_thr, float) else list(iou_thr)
+        res, aps = OrderedDict(), []
+        for t in thrs:
+            ap, _ = eval_map_single_class(results, anns, t)
+            aps.append(ap)
+            res[f'AP{int(t * 100):02d}'] = round(ap, 3)
+        res['mAP'] = sum(aps) / len(aps)
+        return res
+
     def __getitem__(self, idx):
         """Decoded sample (what LoadImageFromFile + LoadAnnotations deliver, before augmentation)."""
         info = self.data_infos[idx]

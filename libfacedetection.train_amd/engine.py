@@ -697,6 +697,12 @@ class YuNetEngine:
         self.plan = None
         self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
         self.use_lanes = False          # head chains of the coarser levels on executor side streams (Plan.__init__)
+        # comm_timing: events around the three collectives of a step (num_pos | bucket A on the side stream |
+        # bucket B + logged scalars) and around the final wait for the side stream; comm_report() turns them
+        # into milliseconds per step, split into EXPOSED (on the launch stream, nothing to hide behind) and
+        # overlapped.  bench.py switches it on for N > 1 so that a scaling run explains its own efficiency.
+        self.comm_timing = False
+        self._comm_events = []
         self.precision = 'fp32'         # 'fp32' | 'bf16' (activation storage + forward matrix instruction)
         self.lib = L.load()
         self._host_idx = {}
@@ -798,10 +804,39 @@ class YuNetEngine:
         self._exec(plan.c_bwd_a, 'yunet_exec(bwd_a)')
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            ea = self._comm_mark(side)
             self._allreduce_mean(gb[cut:])
+            self._comm_mark(side, ('bucket_a', ea))
         self._exec(plan.c_bwd_b, 'yunet_exec(bwd_b)')
+        eb = self._comm_mark(main)
         self._allreduce_mean(gb[:cut])
+        ew = self._comm_mark(main, ('bucket_b', eb))
         main.wait_stream(side)
+        self._comm_mark(main, ('wait_a', ew))
+
+    def _comm_mark(self, stream, close=None):
+        """comm_timing: record an event on `stream`; with close = (name, start event) file the pair."""
+        if not self.comm_timing:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        if close is not None and close[1] is not None:
+            self._comm_events.append((close[0], close[1], ev))
+        return ev
+
+    def comm_report(self, steps):
+        """Milliseconds per step of every timed collective since the last call (synchronises).  exposed =
+        num_pos + bucket B + the wait for bucket A at the end of backward: the time the launch stream spends
+        in or behind communication; bucket A itself runs under the backward kernels of the early stages."""
+        torch.cuda.synchronize(self.device)
+        tot = {}
+        for name, e0, e1 in self._comm_events:
+            tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+        self._comm_events = []
+        per = {k: round(v / max(steps, 1), 4) for k, v in tot.items()}
+        per['exposed_ms_per_step'] = round(sum(per.get(k, 0.0) for k in ('num_pos', 'bucket_b', 'wait_a')), 4)
+        per['overlapped_ms_per_step'] = per.get('bucket_a', 0.0)
+        return per
 
     def _comm_stream(self):
         if getattr(self, '_side', None) is None:
@@ -821,8 +856,10 @@ class YuNetEngine:
     def reduce_num_pos(self, norm):
         """reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74, yunet_head.py:493-497):
         every rank holds num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound."""
-        if self.world_size > 1:
+        if self.world_size > 1 or (self.always_bucket and torch.distributed.is_initialized()):
+            e0 = self._comm_mark(None)
             torch.distributed.all_reduce(norm[0:1], group=self.process_group)
+            self._comm_mark(None, ('num_pos', e0))
 
     def allreduce_grads(self):
         """DDP gradient mean in ONE collective over [logged scalars | flat gradient]

@@ -186,3 +186,129 @@ def wider_evaluation(pred, gt_path, iou_thresh=0.5, return_curves=False):
         aps.append(float(voc_ap(recall, precision)))
         curves.append(np.stack([precision, recall], 1))
     return (aps, curves) if return_curves else aps
+
+
+# ============================================================================ mAP (EvalHook during training)
+# What `EvalHook` reports while training (mmdet/apis/train.py:226-232 -> mmdet/core/evaluation/eval_hooks.py:24-66
+# -> CustomDataset.evaluate, mmdet/datasets/custom.py:310-367 -> eval_map, mmdet/core/evaluation/mean_ap.py:522-686):
+# VOC-style average precision of the single face class at IoU 0.5, "area" mode, ignored GT boxes neither matched
+# nor counted.  Restated for one class, without the multiprocessing pool; same arithmetic and dtypes.
+def bbox_overlaps_np(b1, b2, eps=1e-6):
+    """mmdet/core/evaluation/bbox_overlaps.py:5-65 (mode 'iou', no legacy +1): float32 [n, k]."""
+    b1, b2 = np.asarray(b1, dtype=np.float32).reshape(-1, 4), np.asarray(b2, dtype=np.float32).reshape(-1, 4)
+    if b1.shape[0] * b2.shape[0] == 0:
+        return np.zeros((b1.shape[0], b2.shape[0]), dtype=np.float32)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    xs, ys = np.maximum(b1[:, None, 0], b2[None, :, 0]), np.maximum(b1[:, None, 1], b2[None, :, 1])
+    xe, ye = np.minimum(b1[:, None, 2], b2[None, :, 2]), np.minimum(b1[:, None, 3], b2[None, :, 3])
+    overlap = np.maximum(xe - xs, 0) * np.maximum(ye - ys, 0)
+    union = np.maximum(a1[:, None] + a2[None, :] - overlap, np.float32(eps))
+    return (overlap / union).astype(np.float32)
+
+
+def tpfp_default(dets, gts, gts_ignore, iou_thr=0.5):
+    """mean_ap.py:168-267 without area ranges: (tp, fp) float32 [m] for the detections [m, 5] of one image.
+    A detection whose best-overlapping GT is an ignored box is neither; a second hit on a covered GT is fp."""
+    m = dets.shape[0]
+    tp, fp = np.zeros(m, dtype=np.float32), np.zeros(m, dtype=np.float32)
+    ignore = np.concatenate([np.zeros(gts.shape[0], dtype=bool), np.ones(gts_ignore.shape[0], dtype=bool)])
+    allgt = np.vstack([gts.reshape(-1, 4), gts_ignore.reshape(-1, 4)])
+    if allgt.shape[0] == 0:
+        fp[...] = 1
+        return tp, fp
+    ious = bbox_overlaps_np(dets[:, :4], allgt)
+    best, arg = ious.max(axis=1), ious.argmax(axis=1)
+    covered = np.zeros(allgt.shape[0], dtype=bool)
+    for i in np.argsort(-dets[:, -1]):
+        if best[i] >= iou_thr:
+            g = arg[i]
+            if not ignore[g]:
+                if not covered[g]:
+                    covered[g] = True
+                    tp[i] = 1
+                else:
+                    fp[i] = 1
+        else:
+            fp[i] = 1
+    return tp, fp
+
+
+def average_precision_area(recalls, precisions):
+    """mean_ap.py:13-57, mode 'area' (float32 accumulator like the reference)."""
+    mrec = np.hstack((np.zeros(1, recalls.dtype), recalls, np.ones(1, recalls.dtype)))
+    mpre = np.hstack((np.zeros(1, recalls.dtype), precisions, np.zeros(1, recalls.dtype)))
+    for i in range(mpre.shape[0] - 1, 0, -1):
+        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+    ind = np.where(mrec[1:] != mrec[:-1])[0]
+    return np.float32(np.sum((mrec[ind + 1] - mrec[ind]) * mpre[ind + 1]))
+
+
+def eval_map_single_class(det_results, annotations, iou_thr=0.5):
+    """eval_map (mean_ap.py:522-686) for one class.  det_results: per image [[n, 5] array] (the per-class
+    list of a detector's simple_test) or the [n, 5] array itself; annotations: per image dict(bboxes, labels,
+    bboxes_ignore, labels_ignore) as RetinaFaceDataset.get_ann_info returns.  -> (mAP, dict(num_gts, num_dets,
+    recall, precision, ap))."""
+    assert len(det_results) == len(annotations)
+    dets = [np.asarray(d[0] if isinstance(d, (list, tuple)) else d, dtype=np.float32).reshape(-1, 5) for d in det_results]
+    tps, fps, num_gts = [], [], 0
+    for d, ann in zip(dets, annotations):
+        gts = np.asarray(ann['bboxes'], dtype=np.float32).reshape(-1, 4)
+        ign = np.asarray(ann.get('bboxes_ignore', np.zeros((0, 4))), dtype=np.float32).reshape(-1, 4)
+        t, f = tpfp_default(d, gts, ign, iou_thr)
+        tps.append(t)
+        fps.append(f)
+        num_gts += gts.shape[0]
+    alld = np.vstack(dets) if dets else np.zeros((0, 5), dtype=np.float32)
+    order = np.argsort(-alld[:, -1])
+    tp = np.cumsum(np.hstack(tps)[order]) if alld.shape[0] else np.zeros(0, dtype=np.float32)
+    fp = np.cumsum(np.hstack(fps)[order]) if alld.shape[0] else np.zeros(0, dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    recalls = tp / np.maximum(np.array([num_gts]), eps)      # float64, like the reference's int array / float32 eps
+    precisions = tp / np.maximum(tp + fp, eps)
+    ap = average_precision_area(recalls, precisions)
+    res = dict(num_gts=num_gts, num_dets=int(alld.shape[0]), recall=recalls, precision=precisions, ap=ap)
+    return (float(ap) if num_gts > 0 else 0.0), res
+
+
+def prepare_test_image(img_bgr, scale, device):
+    """The test pipeline of the shipped configs on the device (configs/yunet_n.py:57-86: MultiScaleFlipAug(
+    img_scale, flip=False) -> Resize(keep_ratio=True) -> Normalize(mean 0, std 1) -> Pad(size_divisor 32)):
+    uint8 [h, w, 3] -> (float32 [1, 3, H, W] on the device, img_meta).  mmcv.imrescale semantics for the size
+    (factor = min(long / long_edge, short / short_edge), rounded); scale None keeps the original size."""
+    import torch
+    import torch.nn.functional as F
+    h, w = img_bgr.shape[:2]
+    x = torch.from_numpy(img_bgr).to(device).permute(2, 0, 1)[None].float()
+    if scale is None:
+        nh, nw = h, w
+    else:
+        f = min(max(scale) / max(h, w), min(scale) / min(h, w))
+        nw, nh = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+        x = F.interpolate(x, size=(nh, nw), mode='bilinear', align_corners=False)
+    ph = max(nh, 0 if scale is None else scale[0] if nh <= scale[0] else nh)
+    pw = max(nw, 0 if scale is None else scale[1] if nw <= scale[1] else nw)
+    ph, pw = (ph + 31) // 32 * 32, (pw + 31) // 32 * 32
+    x = F.pad(x, (0, pw - nw, 0, ph - nh)).contiguous()
+    sf = np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32)
+    meta = dict(ori_shape=(h, w, 3), img_shape=(nh, nw, 3), pad_shape=(ph, pw, 3), scale_factor=sf,
+                flip=False, flip_direction='horizontal')
+    return x, meta
+
+
+def single_gpu_test(model, dataset, device, scale=(640, 640), max_images=None):
+    """mmdet/apis/test.py single_gpu_test for this path: eval-mode forward + get_bboxes(rescale=True) per image
+    of a test-mode RetinaFaceDataset -> [[dets [n, 5]]] per image (boxes in original-image coordinates)."""
+    import torch
+    was_training = model.training
+    model.eval()
+    out = []
+    n = len(dataset) if max_images is None else min(len(dataset), max_images)
+    with torch.no_grad():
+        for i in range(n):
+            img, meta = prepare_test_image(dataset.load_image(i), scale, device)
+            meta['ori_filename'] = dataset.data_infos[i]['filename']
+            out.append(model(return_loss=False, rescale=True, img=[img], img_metas=[[meta]])[0])
+    if was_training:
+        model.train()
+    return out

@@ -245,6 +245,55 @@ class CheckpointHook(Hook):
                 os.remove(path)
 
 
+class EvalHook(Hook):
+    """mmdet/core/evaluation/eval_hooks.py:24-66 on this path: every `interval` epochs (by_epoch) or iterations,
+    rank 0 runs the detector in eval mode over the validation set (evaluation.single_gpu_test: the device test
+    pipeline + get_bboxes), calls dataset.evaluate(results, metric=...) and files the numbers in the log
+    (runner.log_buffer entries tagged mode='val').  The shipped configs set interval=1001 (> max_epochs): the hook
+    is registered, as in the reference, and never fires there.  DistEvalHook: the other ranks wait at a barrier
+    (the validation set is small next to an epoch; the reference shards it over ranks)."""
+
+    def __init__(self, dataset, interval=1, by_epoch=True, metric='mAP', start=None, scale=(640, 640),
+                 max_images=None, save_best=None, distributed=False, **eval_kwargs):
+        self.dataset, self.interval, self.by_epoch, self.metric = dataset, int(interval), by_epoch, metric
+        self.start, self.scale, self.max_images, self.distributed = start, scale, max_images, distributed
+        self.eval_kwargs = {k: v for k, v in eval_kwargs.items() if k in ('iou_thr',)}
+        self.best, self.results = None, []
+
+    def _should(self, runner, count):
+        if self.start is not None and count < self.start:
+            return False
+        return count > 0 and count % self.interval == 0
+
+    def after_train_epoch(self, runner):
+        if self.by_epoch and self._should(runner, runner.epoch + 1):
+            self._evaluate(runner)
+
+    def after_train_iter(self, runner):
+        if not self.by_epoch and self._should(runner, runner.iter + 1):
+            self._evaluate(runner)
+
+    def _evaluate(self, runner):
+        from .evaluation import single_gpu_test
+        if runner.rank == 0:
+            target = runner.model.module if hasattr(runner.model, 'module') else runner.model
+            dev = torch.device(runner.device) if not isinstance(runner.device, torch.device) else runner.device
+            if dev.type == 'cuda' and dev.index is None:
+                dev = torch.device('cuda', torch.cuda.current_device())
+            dets = single_gpu_test(target, self.dataset, dev, self.scale, self.max_images)
+            res = self.dataset.evaluate(dets, metric=self.metric, **self.eval_kwargs)
+            done = runner.iter if self.by_epoch else runner.iter + 1          # iterations completed so far
+            entry = dict(mode='val', epoch=runner.epoch + 1, iter=done, **{k: float(v) for k, v in res.items()})
+            runner.log_buffer.append(entry)
+            self.results.append(entry)
+            runner.logger('Epoch(val) [%d][%d]\t%s' % (runner.epoch + 1, len(dets),
+                                                       ', '.join(f'{k}: {float(v):.4f}' for k, v in res.items())))
+            if self.best is None or res.get('mAP', 0.0) > self.best:
+                self.best = res.get('mAP', 0.0)
+        if self.distributed and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+
+
 class LoggerHook(Hook):
     def __init__(self, interval=50, by_epoch=True, **_):
         self.interval, self.by_epoch = interval, by_epoch
@@ -262,7 +311,7 @@ class LoggerHook(Hook):
         dt = (time.time() - self._t0) / self.interval
         self._t0 = time.time()
         rec = dict(lv, iter=runner.iter + 1, epoch=runner.epoch + 1, lr=runner.current_lr()[0], time=dt)
-        if not runner.log_buffer or runner.log_buffer[-1]['iter'] != rec['iter']:
+        if not runner.log_buffer or runner.log_buffer[-1].get('mode') == 'val' or runner.log_buffer[-1]['iter'] != rec['iter']:
             runner.log_buffer.append(rec)            # once per iteration, however many logger hooks
         if runner.rank == 0:
             self.log(runner, rec)
@@ -458,6 +507,22 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
         log_config = dict(log_config, interval=1)          # short smoke runs: log every iteration
     runner.register_training_hooks(cfg.lr_config, optimizer_config, cfg.get('checkpoint_config'), log_config,
                                    cfg.get('momentum_config'), cfg.get('custom_hooks'))
+    # EvalHook (mmdet/apis/train.py:204-232): validate=True and a validation set in the config
+    if validate and cfg.get('data') is not None and cfg.get('data').get('val') is not None:
+        from .builder import build_dataset
+        val_cfg = dict(cfg.get('data')['val'])
+        val_cfg['test_mode'] = True
+        eval_cfg = dict(cfg.get('evaluation', {}))
+        eval_cfg['by_epoch'] = dict(cfg.runner).get('type', 'EpochBasedRunner') != 'IterBasedRunner'
+        scale = None
+        for t in val_cfg.get('pipeline') or []:
+            if t.get('type') == 'MultiScaleFlipAug':
+                scale = tuple(t['img_scale']) if not isinstance(t['img_scale'], list) else tuple(t['img_scale'][0])
+        if os.path.exists(val_cfg.get('ann_file', '')):
+            runner.register_hook(EvalHook(build_dataset(val_cfg), scale=scale or (640, 640), distributed=distributed,
+                                          **eval_cfg), 'LOW')
+        else:
+            log(f"validate: {val_cfg.get('ann_file')} not found -- no EvalHook registered")
     resume_from = cfg.get('resume_from')
     if not resume_from and cfg.get('auto_resume') and cfg.get('work_dir'):
         resume_from = find_latest_checkpoint(cfg.work_dir)

@@ -108,6 +108,7 @@ def _nccl_world1(port, out):
                 eng = model._ensure_engine(dev)
                 eng.always_bucket = True          # two backward segments + RCCL (ncclAvg) at world size 1
                 eng.world_size = 1
+                eng.comm_timing = True            # events around the three collectives (bench.py: N > 1)
             o = ddp.train_step(batch, opt)
             if mode == 'bucketed':
                 # world size 1: the step logs from plan.losses; also route them through the gradient
@@ -119,6 +120,8 @@ def _nccl_world1(port, out):
             logs = {k: float(v) for k, v in o['log_vars'].items()}
         torch.cuda.synchronize()
         eng = model.engine
+        if mode == 'bucketed':
+            res['comm'] = eng.comm_report(2)
         res[mode] = dict(grad=eng.params.grad.detach().cpu().clone(), params=eng.params.data.detach().cpu().clone(),
                          head=eng.params.log_head.detach().cpu().clone(), logs=logs,
                          split=eng.plan.split_off)
@@ -151,6 +154,12 @@ def test_rccl_backend_bucketed_allreduce_world1():
         assert v == pytest.approx(b['logs'][k], rel=1e-6)
     # loss_finalize mirrors cls, bbox, obj, kps, total into the head of the gradient buffer
     assert b['head'][4] == pytest.approx(b['logs']['loss'], rel=1e-6)
+    # comm_report: every collective of the step was timed on its own stream (engine.comm_timing, bench.py N > 1)
+    comm = out['comm']
+    assert {'num_pos', 'bucket_a', 'bucket_b', 'wait_a', 'exposed_ms_per_step', 'overlapped_ms_per_step'} <= set(comm)
+    assert comm['exposed_ms_per_step'] == pytest.approx(comm['num_pos'] + comm['bucket_b'] + comm['wait_a'], abs=1e-3)
+    assert 0 < comm['exposed_ms_per_step'] < 50 and comm['bucket_a'] > 0
+    print('[rccl world 1] comm ms per step:', comm)
 
 
 def test_two_gpus_rccl_if_available():

@@ -294,3 +294,46 @@ data = dict(samples_per_gpu=1, test=dict(type='RetinaFaceDataset',
     assert r.returncode == 0, r.stderr[-1500:]
     again = [float(v) for v in open(tmp_path / 'again' / 'aps').read().strip().split(',')]
     assert again == pytest.approx(aps[2], abs=2e-4)          # text files keep 5 decimals
+
+
+def test_eval_hook_runs_during_training(tmp_path):
+    """train_detector(validate=True) with `evaluation = dict(interval=1, metric='mAP')`: after every epoch the
+    EvalHook runs the eval-mode detector over the validation list (device test pipeline + get_bboxes), calls
+    dataset.evaluate and logs AP50 / mAP; training continues in train mode afterwards.  A detector trained for a
+    couple of thousand iterations on the structured synthetic faces (the bench fixture) scores a non-trivial AP
+    on images painted the same way."""
+    from PIL import Image
+    import yunet_amd
+    import yunet_amd.runner as R
+    import yunet_amd.synthetic as S
+    sd = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yunet_n_synth_trained.pth'),
+                    map_location='cpu', weights_only=False)['state_dict']        # 2000 SGD iterations on such faces
+    b = S.make_batch(6, 320, 320, 31, structured=True)
+    os.makedirs(tmp_path / 'img')
+    lines = []
+    for i in range(6):
+        arr = b['img'][i].permute(1, 2, 0).clamp(0, 255).byte().numpy()           # BGR planes -> HWC
+        Image.fromarray(arr[:, :, ::-1].copy()).save(tmp_path / 'img' / f'{i}.png')
+        lines.append(f'# {i}.png 320 320')
+        for box in b['gt_bboxes'][i]:
+            lines.append('%.2f %.2f %.2f %.2f' % tuple(float(v) for v in box))
+    (tmp_path / 'val.txt').write_text('\n'.join(lines) + '\n')
+    cfg = yunet_amd.Config.fromfile('configs/yunet_n.py')
+    cfg.merge_from_dict(dict(
+        data=dict(samples_per_gpu=8, val=dict(type='RetinaFaceDataset', ann_file=str(tmp_path / 'val.txt'),
+                                              img_prefix=str(tmp_path / 'img'),
+                                              pipeline=[dict(type='MultiScaleFlipAug', img_scale=(320, 320), flip=False, transforms=[])])),
+        evaluation=dict(interval=1, metric='mAP'), runner=dict(type='EpochBasedRunner', max_epochs=2),
+        checkpoint_config=None, work_dir=str(tmp_path / 'work'),
+        log_config=dict(interval=1, hooks=[dict(type='TextLoggerHook')])))
+    cfg.optimizer['lr'] = 1e-5
+    model = yunet_amd.build_detector(cfg.model)
+    model.load_state_dict(sd, strict=True)
+    src = R.SyntheticWiderFace((160, 160), 8, iters_per_epoch=2)
+    lines_out = []
+    hist = R.train_detector(model, src, cfg, validate=True, device='cuda', log=lines_out.append)
+    val = [h for h in hist if h.get('mode') == 'val']
+    assert [v['epoch'] for v in val] == [1, 2] and all(set(v) >= {'AP50', 'mAP'} for v in val)
+    assert all(0.0 <= v['mAP'] <= 1.0 for v in val) and val[0]['mAP'] > 0.2, val
+    assert any(l.startswith('Epoch(val) [1][6]') for l in lines_out)
+    assert model.training and len([h for h in hist if h.get('mode') != 'val']) == 4

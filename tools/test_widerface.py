@@ -21,7 +21,6 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 import yunet_amd  # noqa: E402
 from yunet_amd import evaluation as E  # noqa: E402
@@ -54,26 +53,7 @@ def target_scale(mode):
     raise SystemExit(f'--mode {mode}')
 
 
-def prepare(img_bgr, scale, device):
-    """uint8 [h,w,3] -> (float32 [1,3,H,W] on the device, img_meta).  mmcv.imrescale semantics for the
-    size (rescale_size: factor = min(long/long_edge, short/short_edge), rounded), Pad to the target
-    (or to a multiple of 32), right / bottom, zeros."""
-    h, w = img_bgr.shape[:2]
-    x = torch.from_numpy(img_bgr).to(device).permute(2, 0, 1)[None].float()
-    if scale is None:
-        nh, nw = h, w
-    else:
-        f = min(max(scale) / max(h, w), min(scale) / min(h, w))
-        nw, nh = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
-        x = F.interpolate(x, size=(nh, nw), mode='bilinear', align_corners=False)
-    ph = max(nh, 0 if scale is None else scale[0] if nh <= scale[0] else nh)
-    pw = max(nw, 0 if scale is None else scale[1] if nw <= scale[1] else nw)
-    ph, pw = (ph + 31) // 32 * 32, (pw + 31) // 32 * 32
-    x = F.pad(x, (0, pw - nw, 0, ph - nh)).contiguous()
-    sf = np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32)
-    meta = dict(ori_shape=(h, w, 3), img_shape=(nh, nw, 3), pad_shape=(ph, pw, 3), scale_factor=sf,
-                flip=False, flip_direction='horizontal')
-    return x, meta
+prepare = E.prepare_test_image      # the test pipeline on the device (shared with the EvalHook)
 
 
 def main():

@@ -86,7 +86,7 @@ def main():
                          'SyntheticWiderFace (ready batches) or SyntheticSourceImages (decoded synthetic '
                          'sources + the reference train pipeline on the GPU)')
     meta = dict(config=args.config, seed=seed, CLASSES=('face',))
-    R.train_detector(model, ds, cfg, distributed=distributed, validate=False, meta=meta,
+    R.train_detector(model, ds, cfg, distributed=distributed, validate=not a.no_validate, meta=meta,
                      max_iters=args.max_iters)
 
 
