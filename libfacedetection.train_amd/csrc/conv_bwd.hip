@@ -508,7 +508,9 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 }
             }
         } else if (!(abl & 1)) {
-#pragma unroll 1
+            // 16-channel inputs: one k block per pixel tile -- the wave's pixel tiles are unrolled so that their
+            // read -> transform -> 4 dependent MFMAs -> write chains overlap (rolled, each tile pays the whole latency)
+#pragma unroll (CIN == 16 ? G::MPW : 1)
             for (int mi = 0; mi < G::MPW; ++mi) {
                 const int mt = wid * G::MPW + mi;
                 f32x4 acc[G::NTO];
@@ -699,6 +701,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 const int ca = w1_ci0 + G::MB * (G::LAUNDER ? opaque(l15) : l15) + j;
                 am[j] = s_ci[ca]; as_[j] = s_ci[CIN + ca]; ab[j] = s_ci[2 * CIN + ca];
             }
+            // a single 16 x 16 tile per wave (16 -> 16 units) would be one chain of KSTEPS dependent MFMAs: four
+            // partial accumulators, summed once per tile
+            constexpr int NPART = (G::MB * G::NB == 1) ? 4 : 1;
+            f32x4 part[NPART];
+            if constexpr (NPART > 1) {
+#pragma unroll
+                for (int q = 0; q < NPART; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll 8
             for (int s = 0; s < G::KSTEPS; ++s) {
                 float av[G::MB], bv[G::NB];
@@ -717,10 +727,19 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
 #pragma unroll
                 for (int j = 0; j < G::MB; ++j) {
                     const float a = tin(av[j], am[j], as_[j], ab[j], relu_floor);
+                    if constexpr (NPART > 1) {
+                        part[s % NPART] = mfma16(a, bv[0], part[s % NPART]);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < G::NB; ++i)
-                        gw1[j * G::NB + i] = mfma16(a, bv[i], gw1[j * G::NB + i]);
+                        for (int i = 0; i < G::NB; ++i)
+                            gw1[j * G::NB + i] = mfma16(a, bv[i], gw1[j * G::NB + i]);
+                    }
                 }
+            }
+            if constexpr (NPART > 1) {
+                static_assert(NPART == 1 || G::KSTEPS % 4 == 0, "partial accumulators: whole rounds of four k-steps");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw1[0][r] += (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
             }
         }
         if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
