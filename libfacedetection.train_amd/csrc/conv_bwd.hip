@@ -1230,32 +1230,36 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     };
     using All = std::integral_constant<int, -1>;
     int t = first_tile();
-    if (t < ntiles) issue(t, All{});
 
     // ---- this wave's weight fragments, straight from global memory into registers ------------------------------
     // p = a * W1^T and da = dp * W1: wave `wid` owns output-channel tile nt = wid & 3 of both GEMMs and the pixel
     // tiles 4 * (wid >> 2) .. + 3.  B operand of v_mfma_f32_16x16x32_bf16: lane (l15, g) supplies column l15,
     // k = 32 kb + 8 g .. + 7.
+    // The weight loads (L2 hits after the first workgroups) are issued BEFORE the first tile's 16 loads per thread
+    // and consumed after: vector-memory returns are counted in order, so weights queued behind a cold-start tile
+    // would wait for all of HBM's latency before the first split could run.
     const int nt = wid & 3, mh = wid >> 2;
     u32x4 w1h[2], w1l[2], wth[2], wtl[2];
     {
         const int co = nt * 16 + l15;             // p GEMM: column = output channel, k = input channel
+        const int ci = nt * 16 + l15;             // da GEMM: column = input channel, k = output channel
+        float4 ra[2], rb[2];
+        float rt[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const float4 a = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g);
-            const float4 b = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g + 4);
-            const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            ra[kb] = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g);
+            rb[kb] = *reinterpret_cast<const float4*>(d.w_pw + co * C + 32 * kb + 8 * g + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rt[kb][j] = d.w_pw[(32 * kb + 8 * g + j) * C + ci];
+        }
+        if (t < ntiles) issue(t, All{});
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float w8[8] = {ra[kb].x, ra[kb].y, ra[kb].z, ra[kb].w, rb[kb].x, rb[kb].y, rb[kb].z, rb[kb].w};
             const Split8 sp = split8(w8);
             w1h[kb] = sp.hi; w1l[kb] = sp.lo;
-        }
-        const int ci = nt * 16 + l15;             // da GEMM: column = input channel, k = output channel
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float w8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w8[j] = d.w_pw[(32 * kb + 8 * g + j) * C + ci];
-            const Split8 sp = split8(w8);
-            wth[kb] = sp.hi; wtl[kb] = sp.lo;
+            const Split8 st = split8(rt[kb]);
+            wth[kb] = st.hi; wtl[kb] = st.lo;
         }
     }
     for (int c = tid; c < C; c += NT) s_b1[c] = d.b_pw[c];

@@ -228,8 +228,12 @@ def test_full_step_vs_oracle(kind, h, n, seed, weights):
         assert npos_per_gt > 3.0, f'trained fixture: {npos_per_gt:.2f} positives per GT -- dynamic_k > 1 is not exercised'
 
     # (4) parameter gradients against fp64 (two backward passes through one fp64 forward)
+    # (the fp64 graph of the conv stack costs twice the fp32 oracle step on the host: it is run for the headline
+    #  shape -- both weight sets -- and the other two BASELINE shapes are held to the oracle's fp32 gradients at the
+    #  bar two fp32 evaluations of this stack agree to; YUNET_TEST_FP64_ALL=1 runs the yardstick everywhere)
     need_gb = 0.1 * n * (h / 320.0) ** 2 * 1.3
-    if _avail_gb() > need_gb:
+    want_fp64 = (kind, h, n) == ('n', 320, 256) or bool(os.environ.get('YUNET_TEST_FP64_ALL'))
+    if want_fp64 and _avail_gb() > need_gb:
         sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         leaf64 = {k: sd64[k].clone().requires_grad_(True) for k in keys}
         work64 = dict(sd64)
@@ -255,8 +259,8 @@ def test_full_step_vs_oracle(kind, h, n, seed, weights):
     else:
         # not enough host memory for the fp64 graph: compare with the oracle's fp32 gradients
         # directly, at the looser bar that two fp32 evaluations of this stack agree to
-        print(f'[full step {kind}-{h}-{n}] fp64 yardstick skipped: {_avail_gb():.0f} GB available, '
-              f'{need_gb:.0f} GB needed')
+        print(f'[full step {kind}-{h}-{n}] fp64 yardstick not run ({_avail_gb():.0f} GB available, '
+              f'{need_gb:.0f} GB needed, wanted: {want_fp64})')
         scale = max(float(v.abs().max()) for v in grads_o.values())
         for k in keys:
             err = float((grads_g[k] - grads_o[k]).abs().max())

@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv
 #   3. PMC passes (FETCH_SIZE / WRITE_SIZE, separately)  -> gpurun_out/rNN_pmc_{fetch,write}.csv
 #      over tools/kbench.py on the dominant kernels + a calibration copy of known size
-R=${1:-r02}
+R=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -12,7 +12,16 @@ timeout 600 python bench.py --steps 30 --warmup 10 2>/dev/null | tail -1 > $OUT/
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -o $R -- \
     python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_$R.log 2>&1
-for f in $(find /tmp/prof_$R -name "*kernel_stats.csv"); do cp $f $OUT/${R}_kernel_stats.csv; done
+# keep the kernels of the step: the at::native rows (thousands of calls) are synthetic.render_faces painting the
+# input batches with torch ops BEFORE the warm-up (VERDICT r2 hygiene #10)
+for f in $(find /tmp/prof_$R -name "*kernel_stats.csv"); do
+  python - "$f" "$OUT/${R}_kernel_stats.csv" <<'PY'
+import sys
+rows = open(sys.argv[1]).read().splitlines()
+keep = [rows[0]] + [r for r in rows[1:] if ('_kernel' in r and 'at::native' not in r) or '__amd_rocclr' in r]
+open(sys.argv[2], 'w').write('\n'.join(keep) + '\n')
+PY
+done
 #      3a. over the bench step itself (per-launch means of every kernel of the step)
 #      3b. over tools/kbench.py --calib (a 256 MiB device copy of known size: counter calibration)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -36,11 +45,25 @@ python $GRAFT_REPO_ROOT/tools/pmc_mean.py $OUT/${R}_util.json $UT
 #   5. the second bench line (bf16 activations / bf16 forward matrix instruction, fp32 gradients)
 cd $GRAFT_REPO_ROOT
 timeout 300 python bench.py --dtype bf16 --steps 30 --warmup 10 --no-cpu-baseline --no-gpu-eager 2>/dev/null | tail -1 > $OUT/${R}_bench_bf16.json
-#   6. torch-free kernel A/B at sustained clocks: round-1 backward / forward builds vs this round's
-if [ -f tools/ubench/libyunet_r1.so ]; then
-  REPS=1000 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r1.so libfacedetection.train_amd/libyunet_hip.so:YUNET_BWD_FP32MMA=1 \
-      libfacedetection.train_amd/libyunet_hip.so > $OUT/${R}_bwd_ab.log 2>&1
-  FWD=1 REPS=1000 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r1.so libfacedetection.train_amd/libyunet_hip.so \
-      > $OUT/${R}_fwd_ab.log 2>&1
+#   6. torch-free kernel A/B at sustained clocks (tools/ubench/bwd_ab): the round-2 library (exact-fp32 matrix path =
+#      the yardstick, then its split-bf16 kernel) against this round's dp_bwd64 with 8 waves / 8 x 16 tiles and with
+#      4 waves / 8 x 8 tiles (the wave count is read once per library instance: two copies)
+if [ -f tools/ubench/libyunet_r2.so ]; then
+  cp libfacedetection.train_amd/libyunet_hip.so /tmp/libyunet_nw8.so
+  cp libfacedetection.train_amd/libyunet_hip.so /tmp/libyunet_nw4.so
+  REPS=1000 timeout 300 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r2.so:YUNET_BWD_FP32MMA=1 tools/ubench/libyunet_r2.so \
+      /tmp/libyunet_nw8.so:YUNET_BWD64_NW=8 /tmp/libyunet_nw4.so:YUNET_BWD64_NW=4 libfacedetection.train_amd/libyunet_hip.so \
+      > $OUT/${R}_bwd_ab.log 2>&1
+  SHAPES_ALL=1 ONLY=160 REPS=300 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r2.so libfacedetection.train_amd/libyunet_hip.so \
+      >> $OUT/${R}_bwd_ab.log 2>&1
+fi
+#   7. per-phase cycle counters of dp_bwd64 (a -DDP_BWD_PROF build made by tools/ubench/build_ab.sh prof "-DDP_BWD_PROF"),
+#      whole kernel and with every GEMM / depthwise phase and the global traffic ablated (ABL=63: what staging costs)
+if [ -f tools/ubench/libyunet_prof.so ]; then
+  for a in 0 15 63; do
+    echo "== ABL=$a" >> $OUT/${R}_bwd_phase_cycles.log
+    PROF=1 ABL=$a REPS=50 timeout 200 tools/ubench/bwd_ab.bin tools/ubench/libyunet_r2.so:YUNET_BWD_FP32MMA=1 tools/ubench/libyunet_prof.so \
+        2>&1 | grep -v "total 0" >> $OUT/${R}_bwd_phase_cycles.log
+  done
 fi
 ls -la $OUT | tail -8
