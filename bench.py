@@ -198,7 +198,7 @@ def live_traffic(kernel, a):
         try:
             subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '-o', 'p',
                             '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1',
-                            '--no-cpu-baseline', '--no-roofline', '--kind', a.kind, '--size', str(a.size),
+                            '--no-cpu-baseline', '--no-roofline', '--no-exact-bwd', '--kind', a.kind, '--size', str(a.size),
                             '--batch', str(a.batch), '--weights', a.weights, '--dtype', a.dtype],
                            capture_output=True, timeout=90, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
             csvs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith('counter_collection.csv')]

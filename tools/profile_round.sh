@@ -11,14 +11,15 @@ cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 30 --warmup 10 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -o $R -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/prof_$R.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-exact-bwd > /tmp/prof_$R.log 2>&1
 # keep the kernels of the step: the at::native rows (thousands of calls) are synthetic.render_faces painting the
-# input batches with torch ops BEFORE the warm-up (VERDICT r2 hygiene #10)
+# input batches with torch ops BEFORE the warm-up, the __amd_rocclr_copyBuffer rows its small host-to-device
+# copies (VERDICT r2 hygiene #10)
 for f in $(find /tmp/prof_$R -name "*kernel_stats.csv"); do
   python - "$f" "$OUT/${R}_kernel_stats.csv" <<'PY'
 import sys
 rows = open(sys.argv[1]).read().splitlines()
-keep = [rows[0]] + [r for r in rows[1:] if ('_kernel' in r and 'at::native' not in r) or '__amd_rocclr' in r]
+keep = [rows[0]] + [r for r in rows[1:] if '_kernel' in r and 'at::native' not in r]
 open(sys.argv[2], 'w').write('\n'.join(keep) + '\n')
 PY
 done
@@ -26,7 +27,7 @@ done
 #      3b. over tools/kbench.py --calib (a 256 MiB device copy of known size: counter calibration)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${R}_$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-bwd > /tmp/pmc_$c.log 2>&1
   for f in $(find /tmp/pmc_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_pmc_$c.csv; done
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcc_${R}_$c -o p -- \
       python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 --calib > /tmp/pmcc_$c.log 2>&1
