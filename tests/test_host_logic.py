@@ -272,7 +272,7 @@ def test_bench_byte_model_matches_survey_figures():
     pw_flops = sum(bench.op_flops(op, L) for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
     assert pw_flops / n / 2 / 1e6 == pytest.approx(135.6 * 0.765, rel=0.03)
     # the committed PMC table is found and keyed by the names bench.py prints
-    traffic, src = bench.pmc_traffic('dp_bwd_kernel<64,64,8,16,false,1,false>')
+    traffic, src = bench.pmc_traffic('dp_bwd64_kernel<8,false,false>')
     assert traffic is not None and traffic > 1e8 and src.endswith('_pmc_traffic.json')
 
 
