@@ -154,6 +154,23 @@ def op_flops(op, L):
     return 0
 
 
+def executed_bf16(name, alg_tflops, dtype):
+    """The bf16 matrix work a split-bf16 kernel EXECUTES for its algorithmic fp32 GEMM FLOPs, against the dense
+    bf16 peak (= what MfmaUtil measures): the fp32 forward of 32 / 64-channel inputs runs 6 bf16 products per
+    algorithmic product (exact 3-way split), dp_bwd64 runs 3 GEMMs (p recomputed, dW1, da) x 3 products for its
+    2 algorithmic GEMMs; None for kernels on the exact fp32 instruction."""
+    if name.startswith('dp_bwd64_kernel') or (name.startswith('dp_bwd_kernel<64,64') and ',1,' in name):
+        mult, what = 1.5 * 3, '3 GEMMs (p recomputed, dW1, da) x 3 bf16 MFMA products each'
+    elif dtype == 'f32' and (name.startswith('dp_fwd_kernel<64,') or name.startswith('dp_fwd_kernel<32,')):
+        mult, what = 6.0, 'exact 3-way split: 6 bf16 MFMA products per algorithmic product'
+    elif dtype == 'bf16' and (name.startswith('dp_fwd_kernel<64,') or name.startswith('dp_fwd_kernel<32,')):
+        mult, what = 1.0, 'one bf16 MFMA product per algorithmic product'
+    else:
+        return None
+    return {'achieved': round(alg_tflops * mult, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+            'frac': round(alg_tflops * mult / MFMA_BF16_PEAK_TFLOPS, 4), 'what': what + ' vs the dense bf16 peak'}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/rNN_pmc_traffic.json, written by tools/profile_round.sh + tools/pmc_summary.py:
@@ -570,10 +587,7 @@ def main():
             'mfma': {'achieved': round(tflops, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
                      'what': 'algorithmic fp32-equivalent GEMM FLOPs vs the fp32 MFMA peak',
-                     'executed_bf16': ({'achieved': round(tflops * 1.5 * 3, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
-                                        'frac': round(tflops * 1.5 * 3 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                        'what': '3 GEMMs (p recomputed, dW1, da) x 3 bf16 MFMA products each vs the dense bf16 peak'}
-                                       if ',1,' in name else None)},
+                     'executed_bf16': executed_bf16(name, tflops, a.dtype)},
             'launches_per_step': top['launches'], 'avg_launch_ms': round(per_launch_ms, 4),
             # the same kernel instance per feature-map size (the step average above mixes them)
             'by_shape': {k: {'launches': v['launches'], 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
