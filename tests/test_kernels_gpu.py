@@ -55,9 +55,11 @@ SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5),
 #   (2, 64, 96), (1, 160, 160): W >= 64 and H >= 32 -> the 16x32 "big" tile of the 16->16 units;
 #   (40, 80, 80): 2000 tiles of 8x16 > the persistent grid (256 workgroups backward, <= 1024
 #   forward) -> every workgroup walks >= 3 tiles through the issue(t + gridDim.x) prefetch path;
-#   (70, 20, 20): packed canvas with 5 canvas rows -> 30 x 10 = 300 packed tiles > 256 workgroups.
+#   (70, 20, 20): packed canvas with 5 canvas rows -> 30 x 10 = 300 packed tiles > 256 workgroups;
+#   (40, 40, 40): width a multiple of 8 but not of 16 -> dp_bwd64 on 8 x 8 tiles with 4 waves, two workgroups per
+#   CU (round 3): 1000 tiles > the 512-workgroup grid, the one-float-per-thread remainder of its halo.
 BIG_SHAPES = {(16, 16): [(2, 64, 96), (1, 160, 160), (9, 96, 128)],
-              (64, 64): [(40, 80, 80), (70, 20, 20)],
+              (64, 64): [(40, 80, 80), (70, 20, 20), (40, 40, 40)],
               (16, 64): [(40, 80, 80)],
               (64, 16): [(40, 80, 80), (70, 20, 20)]}
 
@@ -234,7 +236,7 @@ def test_pool_fwd_bwd(c):
 
 
 @pytest.mark.parametrize('ci,c,n,h,w', [(16, 16, 2, 64, 96), (16, 16, 1, 160, 160), (64, 64, 3, 40, 48),
-                                        (64, 64, 20, 80, 80), (32, 64, 3, 40, 48)])
+                                        (64, 64, 20, 80, 80), (32, 64, 3, 40, 48), (64, 64, 12, 40, 40)])
 def test_fused_pooling(ci, c, n, h, w):
     """unit P -> BN -> ReLU -> max_pool2d(2) -> unit Q without a pooling kernel and without a full-size
     gradient of P's output: P's forward also writes the raw window winners + their positions (some gammas are
