@@ -2104,9 +2104,13 @@ __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const Yunet
 
 #endif
 
+// Grid of the element-wise backward kernels (pool / upsample-add).  Every workgroup ends with 2 * C fp64 atomics on
+// the producer's BN-backward sums -- the same 128 addresses for the whole launch: with 2048 workgroups those 262 k
+// same-address atomics, not the 59 - 370 MB of traffic, set the time (pool_bwd + upadd_bwd 0.260 ms per step).
+// Measured: cap 1024 0.223 ms, 768 0.213, 512 0.216, 384 0.242, 256 0.295 (too few waves in flight).
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+    return (int)(b < 1 ? 1 : (b > 768 ? 768 : b));
 }
 
 }  // namespace
