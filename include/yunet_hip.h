@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 4
+#define YUNET_ABI_VERSION 5
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -36,12 +36,18 @@ extern "C" {
  * In backward, consumers accumulate `bstats` = {sum dy[C], sum dy*xhat[C]} (fp64), i.e.
  * d(beta) and d(gamma); the producer's backward turns dy into dz with them. */
 typedef struct YunetBN {
-    const double* stats;   /* [2*C] forward sums (zeroed before the step)            */
-    double* bstats;        /* [2*C] backward sums (zeroed before the step) or NULL    */
+    const double* stats;   /* [slots][2*C] forward sums (zeroed before the step)      */
+    double* bstats;        /* [slots][2*C] backward sums (zeroed before the step) or NULL */
     const float* gamma;    /* [C]                                                     */
     const float* beta;     /* [C]                                                     */
     int32_t count;         /* N*H*W of the normalised tensor                          */
     float eps;
+    int32_t slots;         /* replicas of the sum blocks (0 and 1: one).  Workgroup b adds its partial sums
+                            * into replica b % slots and every reader adds the replicas up: the fp64 atomics
+                            * that end a kernel spread over `slots` times as many cache lines (at the 10 x 10
+                            * and 20 x 20 levels ~250 workgroups x 128 atomics on eight lines cost 4-5 us of a
+                            * 14-30 us launch)                  */
+    int32_t reserved_;
 } YunetBN;
 
 /* Input transform of a fused unit (how it reads its input tensor). */
@@ -141,13 +147,13 @@ int yunet_upadd_bwd(const float* za, const YunetBN* bna, const float* zb, const 
 int yunet_bn_update_running(const double* stats, float* running_mean, float* running_var,
                             int C, int count, float momentum, void* stream);
 
-/* Final BN parameter gradients: d(gamma) = bstats[C:2C], d(beta) = bstats[0:C]. */
+/* Final BN parameter gradients: d(gamma) = bstats[C:2C], d(beta) = bstats[0:C] (a single-replica block). */
 int yunet_bn_param_grad(const double* bstats, float* dgamma, float* dbeta, int C,
                         int accumulate, void* stream);
 
-/* All BatchNorm layers of the model in ONE launch.  table (device, int32 [n,6]) rows:
+/* All BatchNorm layers of the model in ONE launch.  table (device, int32 [n,7]) rows:
  * {stats offset (doubles, into stats_base), C, count, running offset (floats),
- *  dgamma offset, dbeta offset (floats, into grad_base)}.
+ *  dgamma offset, dbeta offset (floats, into grad_base), slots (YunetBN::slots of the [slots][2C] block)}.
  * mode 0: running_mean/var update from the forward sums at stats_base + off;
  * mode 1: d(gamma), d(beta) from the backward sums at stats_base + off;
  * mode 2: eval() -- WRITES sums at stats_base + off whose mean / variance equal the running

@@ -24,7 +24,8 @@ OP_LANE, MAX_LANES = 10, 2          # YunetOp.i[OP_LANE]: side stream of the op 
 
 class YunetBN(C.Structure):
     _fields_ = [('stats', C.c_void_p), ('bstats', C.c_void_p), ('gamma', C.c_void_p),
-                ('beta', C.c_void_p), ('count', C.c_int32), ('eps', C.c_float)]
+                ('beta', C.c_void_p), ('count', C.c_int32), ('eps', C.c_float),
+                ('slots', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class YunetDP(C.Structure):
@@ -141,7 +142,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 4:
+    if lib.yunet_abi_version() != 5:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -24,14 +24,14 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 __global__ void bn_batch_kernel(const int32_t* __restrict__ table, const double* __restrict__ stats_base,
                                 float* __restrict__ rm, float* __restrict__ rv, float momentum,
                                 float* __restrict__ grad_base, int mode) {
-    const int32_t* t = table + blockIdx.x * 6;
-    const int C = t[1], count = t[2];
+    const int32_t* t = table + blockIdx.x * 7;
+    const int C = t[1], count = t[2], slots = t[6];
     const double* st = stats_base + t[0];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         if (mode == 0) {
             const double inv = 1.0 / (double)count;
-            const double mean = st[c] * inv;
-            double var = st[C + c] * inv - mean * mean;
+            const double mean = bn_sum(st, slots, C, c) * inv;
+            double var = bn_sum(st, slots, C, C + c) * inv - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
             float* m = rm + t[3];
@@ -39,8 +39,8 @@ __global__ void bn_batch_kernel(const int32_t* __restrict__ table, const double*
             m[c] = (1.0f - momentum) * m[c] + momentum * (float)mean;
             v[c] = (1.0f - momentum) * v[c] + momentum * (float)unb;
         } else if (mode == 1) {
-            grad_base[t[5] + c] = (float)st[c];        // d(beta)  = sum dy
-            grad_base[t[4] + c] = (float)st[C + c];    // d(gamma) = sum dy * xhat
+            grad_base[t[5] + c] = (float)bn_sum(st, slots, C, c);        // d(beta)  = sum dy
+            grad_base[t[4] + c] = (float)bn_sum(st, slots, C, C + c);    // d(gamma) = sum dy * xhat
         } else {
             // mode 2, eval(): synthesise the sums whose mean / biased variance are the RUNNING
             // statistics, so the train-mode kernels (which derive their coefficients from the
@@ -49,6 +49,7 @@ __global__ void bn_batch_kernel(const int32_t* __restrict__ table, const double*
             const double m = (double)rm[t[3] + c], v = (double)rv[t[3] + c];
             w[c] = m * (double)count;
             w[C + c] = (v + m * m) * (double)count;
+            for (int k = 1; k < slots; ++k) w[k * 2 * C + c] = 0.0, w[k * 2 * C + C + c] = 0.0;
         }
     }
 }

@@ -108,10 +108,27 @@ struct BNCoef {
     float mean, scale, beta, invstd;
     float mean_lo;   // mean = mean + mean_lo to ~fp64 accuracy (see bn_center)
 };
+// sum i of a [slots][2C] block of BN sums (YunetBN::slots), and the replica workgroup blockIdx.x adds into
+// The first eight replicas are loaded unconditionally (replicas past `slots` re-read replica 0 and count as
+// zero): eight independent loads in flight.  As a loop over `slots` the loads were issued one latency after the
+// other at the start of every workgroup, and eight replicas made the 20 x 20 backward launch 9 us SLOWER.
+__device__ __forceinline__ double bn_sum(const double* __restrict__ s, int slots, int C, int i) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s[(k < slots ? k : 0) * 2 * C + i];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = k < slots ? v[k] : 0.0;
+    double r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int k = 8; k < slots; ++k) r += s[k * 2 * C + i];
+    return r;
+}
+__device__ __forceinline__ double* bn_slot(const double* base, int slots, int C) {
+    return const_cast<double*>(base) + (slots > 1 ? (int)(blockIdx.x % (unsigned)slots) * 2 * C : 0);
+}
 __device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
     const double inv = 1.0 / (double)bn.count;
-    const double mean = bn.stats[c] * inv;
-    double var = bn.stats[C + c] * inv - mean * mean;
+    const double mean = bn_sum(bn.stats, bn.slots, C, c) * inv;
+    double var = bn_sum(bn.stats, bn.slots, C, C + c) * inv - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     BNCoef k;
     k.mean = (float)mean;
@@ -133,10 +150,10 @@ __device__ __forceinline__ BNBwd bn_bwd_coef(const YunetBN& bn, int C, int c) {
     k.mean = f.mean;
     k.invstd = f.invstd;
     k.k1 = f.scale;
-    const double c1 = bn.bstats[c] * inv;
+    const double c1 = bn_sum(bn.bstats, bn.slots, C, c) * inv;
     k.c1 = (float)c1;
     k.c1_lo = (float)(c1 - (double)k.c1);
-    k.c2 = (float)(bn.bstats[C + c] * inv);
+    k.c2 = (float)(bn_sum(bn.bstats, bn.slots, C, C + c) * inv);
     k.mean_lo = f.mean_lo;
     return k;
 }

@@ -953,7 +953,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     __syncthreads();
     reduce_pass(1, 5);
     // (c) BN-backward sums of the producer: one global fp64 atomic per channel
-    if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(d.in_bn.bstats + tid, s_bst[tid]);
+    if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * CIN) atomic_add_f64(bn_slot(d.in_bn.bstats, d.in_bn.slots, CIN) + tid, s_bst[tid]);
 #ifdef DP_BWD_PROF
     if (prof_on && threadIdx.x == 0) d.prof[blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - prof_t1;
 #endif
@@ -1710,7 +1710,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     if (bn_in && d.dx && d.in_bn.bstats && tid < 2 * C) {
         double v = s_bst[tid];
         if constexpr (MH == 2) v += s_bst[2 * C + tid];
-        atomic_add_f64(d.in_bn.bstats + tid, v);
+        atomic_add_f64(bn_slot(d.in_bn.bstats, d.in_bn.slots, C) + tid, v);
     }
     __syncthreads();
     my[0] = gw2[6]; my[1] = gw2[7]; my[2] = gw2[8]; my[3] = gb1; my[4] = gb2;
@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const act_t* __restrict__
         const int q = c >> 2, kk = (c & 3) + 4 * which;
         double v = 0.0;
         for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];
-        atomic_add_f64(bn.bstats + which * C + c, v);
+        atomic_add_f64(bn_slot(bn.bstats, bn.slots, C) + which * C + c, v);
     }
 }
 
@@ -2032,7 +2032,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
         *dstb = v;
     }
     __shared__ double red[256 * 8];
-#define UPADD_FLUSH(SRC, DST)                                                        \
+#define UPADD_FLUSH(SRC, DST, SLOTS)                                                  \
     __syncthreads();                                                                 \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = SRC[i]; \
     __syncthreads();                                                                 \
@@ -2041,10 +2041,10 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
         const int q = c >> 2, kk = (c & 3) + 4 * which;                              \
         double v = 0.0;                                                              \
         for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];          \
-        atomic_add_f64(DST + which * C + c, v);                                      \
+        atomic_add_f64(bn_slot(DST, SLOTS, C) + which * C + c, v);                   \
     }
-    UPADD_FLUSH(bsa, bna.bstats)
-    UPADD_FLUSH(bsb, bnb.bstats)
+    UPADD_FLUSH(bsa, bna.bstats, bna.slots)
+    UPADD_FLUSH(bsb, bnb.bstats, bnb.slots)
 #undef UPADD_FLUSH
 }
 

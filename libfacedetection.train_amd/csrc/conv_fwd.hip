@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
             const int q = c >> 2, k = (c & 3) + 4 * which;
             double v = 0.0;
             for (int p = 0; p < G::PG; ++p) v += red[(p * G::C4O + q) * 8 + k];
-            atomic_add_f64(const_cast<double*>(d.out_bn.stats) + which * COUT + c, v);
+            atomic_add_f64(bn_slot(d.out_bn.stats, d.out_bn.slots, COUT) + which * COUT + c, v);
         }
     }
 }

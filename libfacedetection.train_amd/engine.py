@@ -25,6 +25,11 @@ from . import kernels as K
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# Replicas of every BatchNorm layer's fp64 sum blocks (YunetBN::slots).  A kernel ends with one fp64 atomic
+# per channel and workgroup; at the packed 20 x 20 / 10 x 10 levels ~250 workgroups hit the same eight cache
+# lines and that tail was 4-5 us of a 14-35 us launch.  Eight replicas remove it (tools/ubench/bwd_ab.cpp,
+# DESIGN.md section 7); the readers add the replicas up.
+BN_SLOTS = max(1, int(os.environ.get('YUNET_BN_SLOTS', '8')))
 LOG_HEAD = 8          # floats in front of the flat gradient: cls, bbox, obj, kps, total, 3 spare
 
 
@@ -205,7 +210,7 @@ class _BNRef:
 
     def c_struct(self):
         return L.YunetBN(self.stats.data_ptr(), self.bstats.data_ptr(), self.gamma_ptr,
-                         self.beta_ptr, self.count, BN_EPS)
+                         self.beta_ptr, self.count, BN_EPS, BN_SLOTS)
 
 
 _NULL_BN = L.YunetBN(None, None, None, None, 1, BN_EPS)
@@ -232,20 +237,22 @@ class Plan:
         f32 = dict(device=dev, dtype=torch.float32)
 
         # ---- BN statistic buffers: one fp64 block, zeroed by a single memset per step
-        tot_c = sum(fp.bn_channels)
+        # (every layer's sums are BN_SLOTS replicas [BN_SLOTS, 2c]: YunetBN::slots)
+        tot_c = sum(fp.bn_channels) * BN_SLOTS
         self.stats = torch.zeros(4 * tot_c, device=dev, dtype=torch.float64)
         self.bn = {}
         o = 0
         for name, c in zip(lay.bn_names, fp.bn_channels):
             g_off = lay.entries[name + '.weight'][0]
             b_off = lay.entries[name + '.bias'][0]
-            self.bn[name] = dict(c=c, stats=self.stats[o:o + 2 * c],
-                                 bstats=self.stats[2 * tot_c + o:2 * tot_c + o + 2 * c],
+            c2 = 2 * c * BN_SLOTS
+            self.bn[name] = dict(c=c, stats=self.stats[o:o + c2].view(BN_SLOTS, 2 * c),
+                                 bstats=self.stats[2 * tot_c + o:2 * tot_c + o + c2].view(BN_SLOTS, 2 * c),
                                  gamma=fp.data.data_ptr() + 4 * g_off,
                                  beta=fp.data.data_ptr() + 4 * b_off,
                                  dgamma=fp.grad.data_ptr() + 4 * g_off,
                                  dbeta=fp.grad.data_ptr() + 4 * b_off)
-            o += 2 * c
+            o += c2
         self.ops_memset_stats = self._op(L.OP_MEMSET, p=[self.stats.data_ptr()],
                                          i=self._split64(self.stats.numel() * 8))
         self.fwd_a.append(self.ops_memset_stats)
@@ -368,9 +375,9 @@ class Plan:
             cnt = self.bn_count[name]
             g_off = lay.entries[name + '.weight'][0]
             b_off = lay.entries[name + '.bias'][0]
-            rows_f.append([so, c, cnt, fp.bn_offset[name], g_off, b_off])
-            rows_b.append([2 * tot_c + so, c, cnt, fp.bn_offset[name], g_off, b_off])
-            so += 2 * c
+            rows_f.append([so, c, cnt, fp.bn_offset[name], g_off, b_off, BN_SLOTS])
+            rows_b.append([2 * tot_c + so, c, cnt, fp.bn_offset[name], g_off, b_off, BN_SLOTS])
+            so += 2 * c * BN_SLOTS
         self.bn_table_f = torch.tensor(rows_f, dtype=torch.int32).to(dev)
         self.bn_table_b = torch.tensor(rows_b, dtype=torch.int32).to(dev)
         self.fwd_b.append(self._op(
@@ -497,7 +504,7 @@ class Plan:
         self.bn_count[name] = count
         b = self.bn[name]
         return L.YunetBN(b['stats'].data_ptr(), b['bstats'].data_ptr(), b['gamma'], b['beta'],
-                         count, BN_EPS)
+                         count, BN_EPS, BN_SLOTS)
 
     def _new_t(self, n, h, w, c, bn_name=None):
         buf = torch.empty(n, h, w, c, device=self.eng.device, dtype=self.act_dtype)

@@ -44,15 +44,17 @@ def _chk_f32(*ts):
 class BN:
     """Python-side YunetBN: keeps the tensors alive while the descriptor is in use."""
 
-    def __init__(self, stats, gamma, beta, count, eps=1e-5, bstats=None):
-        assert stats.dtype == torch.float64 and stats.numel() == 2 * gamma.numel()
+    def __init__(self, stats, gamma, beta, count, eps=1e-5, bstats=None, slots=1):
+        # slots > 1: stats / bstats are [slots, 2C] replica blocks (YunetBN::slots); the sums are their column sums
+        assert stats.dtype == torch.float64 and stats.numel() == slots * 2 * gamma.numel()
+        assert bstats is None or bstats.numel() == slots * 2 * gamma.numel()
         self.stats, self.gamma, self.beta, self.bstats = stats, gamma, beta, bstats
-        self.count, self.eps = int(count), float(eps)
+        self.count, self.eps, self.slots = int(count), float(eps), int(slots)
 
     def c(self):
         return L.YunetBN(self.stats.data_ptr(), self.bstats.data_ptr() if self.bstats is not None
                          else None, self.gamma.data_ptr(), self.beta.data_ptr(), self.count,
-                         self.eps)
+                         self.eps, self.slots)
 
 
 _NULL_BN = L.YunetBN(None, None, None, None, 1, 1e-5)

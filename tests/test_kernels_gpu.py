@@ -340,6 +340,77 @@ def test_upadd_fwd_bwd():
     assert rel_err(bnb.bstats, torch.cat([yb.grad.sum(dim=(0, 2, 3)), (yb.grad * xhb).sum(dim=(0, 2, 3))])) < 5e-5
 
 
+def _replicas(v, slots, g):
+    """[2C] sums -> [slots, 2C] replica blocks that add up to v (unequal shares, one of them negative)."""
+    wts = torch.rand(slots, 1, generator=g, dtype=torch.float64) + 0.1
+    wts = wts / wts.sum()
+    wts[0] -= 0.5
+    wts[1] += 0.5
+    return (wts.to(v.device) * v.view(1, -1)).contiguous()
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(64, 64, 70, 20, 20), (64, 64, 3, 40, 48), (16, 64, 2, 32, 32),
+                                            (64, 16, 5, 20, 20), (16, 16, 2, 64, 96)])
+def test_bn_sum_replicas(cin, cout, n, h, w):
+    """YunetBN::slots: the sum blocks as several replicas (workgroup b adds into replica b % slots, readers add
+    the replicas up) give the results of the single-block layout -- forward, backward, pool, upsample-add."""
+    k = K()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    S = 4
+    x = nhwc(torch.randn(n, cin, h, w, generator=g) * 2 + 0.5).to(DEV)
+    w_pw, b_pw, w_dw, b_dw = [t.to(DEV) for t in mk_unit(cin, cout, g)]
+    w_pw, w_dw = w_pw.view(cout, cin).contiguous(), w_dw.view(cout, 9).contiguous()
+    gi, bi = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * .2).to(DEV)
+    go, bo = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * .2).to(DEV)
+    dy = nhwc(torch.randn(n, cout, h, w, generator=g)).to(DEV)
+    sx = stats_of(x)
+    res = {}
+    for slots in (1, S):
+        rep = (lambda v: v.clone()) if slots == 1 else (lambda v: _replicas(v, slots, g))
+        zero = lambda c: torch.zeros(slots * 2 * c, dtype=torch.float64, device=DEV)
+        in_bn = k.BN(rep(sx), gi, bi, n * h * w, bstats=zero(cin), slots=slots)
+        out_bn = k.BN(zero(cout), go, bo, n * h * w, slots=slots) if cout != 16 or cin != 64 else None
+        z = k.dp_fwd(x, w_pw, b_pw, w_dw, b_dw, in_bn, out_bn)
+        torch.cuda.synchronize()
+        sz = stats_of(z)
+        if out_bn is not None:
+            got = out_bn.stats.view(slots, -1)
+            assert rel_err(got.sum(0), sz) < 2e-5
+            if slots > 1 and n * h * w >= 4 * 512:   # more workgroups than replicas: every replica was written
+                assert bool((got[:, cout:] > 0).all())
+        dy_scale = None
+        if out_bn is not None:
+            dyd = dy.double()
+            mean = sz[:cout] / (n * h * w)
+            var = sz[cout:] / (n * h * w) - mean * mean
+            xhat = (z.double() - mean) / torch.sqrt(var + 1e-5)
+            mask = (xhat * go.double() + bo.double()) > 0
+            dym = dyd * mask
+            bst = torch.cat([dym.sum(dim=(0, 1, 2)), (dym * xhat).sum(dim=(0, 1, 2))])
+            out_bn = k.BN(rep(sz), go, bo, n * h * w, bstats=rep(bst), slots=slots)
+        else:
+            dy_scale = torch.ones(cout, device=DEV)
+        r = k.dp_bwd(x, w_pw, b_pw, w_dw, b_dw, z, dy, in_bn, out_bn, dy_scale=dy_scale)
+        torch.cuda.synchronize()
+        res[slots] = [z] + [t.clone() for t in r] + [in_bn.bstats.view(slots, -1).sum(0)]
+        if cin == cout:        # the element-wise kernels that read and write the same blocks
+            bn_p = k.BN(rep(sx), gi, bi, n * h * w, bstats=zero(cin), slots=slots)
+            pooled = k.pool_fwd(x, bn_p)
+            dpool = k.pool_bwd(x, bn_p, torch.ones_like(pooled) * 0.5)
+            bn_a = k.BN(rep(sx), gi, bi, n * h * w, bstats=zero(cin), slots=slots)
+            bn_b = k.BN(rep(stats_of(pooled)), gi, bi, n * h * w // 4, bstats=zero(cin), slots=slots)
+            up = k.upadd_fwd(x, bn_a, pooled, bn_b)
+            dxa, dxb = k.upadd_bwd(x, bn_a, pooled, bn_b, dy[..., :cin].contiguous())
+            torch.cuda.synchronize()
+            res[slots] += [pooled, dpool, bn_p.bstats.view(slots, -1).sum(0), up, dxa, dxb,
+                           bn_a.bstats.view(slots, -1).sum(0), bn_b.bstats.view(slots, -1).sum(0)]
+    for i, (a, b) in enumerate(zip(res[1], res[S])):
+        if i == 5 and not (cout == 16 and cin == 64):
+            continue      # d(depthwise bias) in front of a BatchNorm is identically zero: rounding noise in both
+        # the replica shares add up to the sums to 1e-16; the coefficients derived from them agree to fp32 rounding
+        assert rel_err(b, a) < 5e-6, i
+
+
 def test_bn_running_and_param_grad():
     k = K()
     g = torch.Generator().manual_seed(5)

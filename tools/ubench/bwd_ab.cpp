@@ -151,11 +151,18 @@ int main(int argc, char** argv) {
         }
         float *dx_x = dev(x), *dz = dev(z), *ddy = dev(dy), *dwp = dev(wp), *dbp = dev(bp), *dwd = dev(wd),
               *dbd = dev(bd), *dgi = dev(gi), *dbi = dev(bi), *dgo = dev(go), *dbo = dev(bo);
-        double *dsin = dev(sin), *dsout = dev(sout), *dbso = dev(bso);
+        // SLOTS=<n>: every BN sum block as n replicas (YunetBN::slots); inputs carry their sums in replica 0
+        const int slots = getenv("SLOTS") ? atoi(getenv("SLOTS")) : 1;
+        auto padded = [&](std::vector<double> v) { v.resize(v.size() * slots, 0.0); return v; };
+        auto fold = [&](std::vector<double>& v, size_t n) {
+            for (int k = 1; k < slots; ++k) for (size_t i = 0; i < n; ++i) v[i] += v[k * n + i];
+            v.resize(n);
+        };
+        double *dsin = dev(padded(sin)), *dsout = dev(padded(sout)), *dbso = dev(padded(bso));
         float* ddx;
         CK(hipMalloc(&ddx, px * ci * 4));
         double* dbsi;
-        CK(hipMalloc(&dbsi, 2 * ci * 8));
+        CK(hipMalloc(&dbsi, 2 * ci * 8 * slots));
         const int width = co * ci + co + co * 9 + co;
         std::vector<double> ref_dx, ref_w, ref_b;
         if (getenv("FWD")) {
@@ -163,7 +170,7 @@ int main(int argc, char** argv) {
             float* dzo;
             CK(hipMalloc(&dzo, px * co * 4));
             double* dst;
-            CK(hipMalloc(&dst, 2 * co * 8));
+            CK(hipMalloc(&dst, 2 * co * 8 * slots));
             std::vector<double> rz, rs;
             for (size_t vi = 0; vi < vs.size(); ++vi) {
                 Variant& v = vs[vi];
@@ -174,18 +181,19 @@ int main(int argc, char** argv) {
                 d.in_transform = YUNET_T_BNRELU; d.out_has_bn = 1;
                 d.x_img_stride = (int64_t)H * W * ci; d.z_img_stride = (int64_t)H * W * co;
                 d.x = dx_x;
-                d.in_bn = YunetBN{dsin, nullptr, dgi, dbi, (int32_t)px, 1e-5f};
+                d.in_bn = YunetBN{dsin, nullptr, dgi, dbi, (int32_t)px, 1e-5f, slots};
                 d.w_pw = dwp; d.b_pw = dbp; d.w_dw = dwd; d.b_dw = dbd;
                 d.z = dzo;
-                d.out_bn = YunetBN{dst, nullptr, dgo, dbo, (int32_t)px, 1e-5f};
-                CK(hipMemsetAsync(dst, 0, 2 * co * 8, st));
+                d.out_bn = YunetBN{dst, nullptr, dgo, dbo, (int32_t)px, 1e-5f, slots};
+                CK(hipMemsetAsync(dst, 0, 2 * co * 8 * slots, st));
                 int rc = v.fwd(&d, st);
                 CK(hipStreamSynchronize(st));
                 if (rc != 0) { printf("%-40s fwd rc=%d\n", v.name.c_str(), rc); continue; }
                 std::vector<float> hz(px * co);
-                std::vector<double> hs(2 * co);
+                std::vector<double> hs(2 * co * slots);
                 CK(hipMemcpy(hz.data(), dzo, hz.size() * 4, hipMemcpyDeviceToHost));
                 CK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+                fold(hs, 2 * co);
                 std::vector<double> vz(hz.begin(), hz.end());
                 for (int i = 0; i < 3; ++i) v.fwd(&d, st);
                 CK(hipEventRecord(e0, st));
@@ -220,10 +228,10 @@ int main(int argc, char** argv) {
             d.in_transform = YUNET_T_BNRELU; d.out_has_bn = 1; d.accumulate_dx = 0;
             d.x_img_stride = (int64_t)H * W * ci; d.z_img_stride = (int64_t)H * W * co;
             d.x = dx_x;
-            d.in_bn = YunetBN{dsin, dbsi, dgi, dbi, (int32_t)px, 1e-5f};
+            d.in_bn = YunetBN{dsin, dbsi, dgi, dbi, (int32_t)px, 1e-5f, slots};
             d.w_pw = dwp; d.b_pw = dbp; d.w_dw = dwd; d.b_dw = dbd;
             d.z = dz;
-            d.out_bn = YunetBN{dsout, dbso, dgo, dbo, (int32_t)px, 1e-5f};
+            d.out_bn = YunetBN{dsout, dbso, dgo, dbo, (int32_t)px, 1e-5f, slots};
             d.dy = ddy; d.dy_scale = nullptr; d.dx = ddx;
             d.wgrad_partials = dpart; d.wgrad_blocks = blocks; d.prof = nullptr;
             // ABL=<mask>: the kernel's debug ablation mask (1 p GEMM, 2 depthwise, 4 dW1, 8 da, 16 dx
@@ -237,7 +245,7 @@ int main(int argc, char** argv) {
                 if (getenv("ABL"))     // dp_bwd64 profile builds: ablation mask in the low bits of the aligned pointer
                     d.prof = (unsigned long long*)((uintptr_t)dprof | ((uintptr_t)atoll(getenv("ABL")) & 63));
             }
-            CK(hipMemsetAsync(dbsi, 0, 2 * ci * 8, st));
+            CK(hipMemsetAsync(dbsi, 0, 2 * ci * 8 * slots, st));
             int rc = v.bwd(&d, st);
             CK(hipStreamSynchronize(st));
             if (rc != 0) {
@@ -246,10 +254,11 @@ int main(int argc, char** argv) {
             }
             // results of this single launch
             std::vector<float> hdx(px * ci), hp((size_t)blocks * width);
-            std::vector<double> hb(2 * ci);
+            std::vector<double> hb(2 * ci * slots);
             CK(hipMemcpy(hdx.data(), ddx, hdx.size() * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hp.data(), dpart, hp.size() * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hb.data(), dbsi, hb.size() * 8, hipMemcpyDeviceToHost));
+            fold(hb, 2 * ci);
             std::vector<double> vdx(hdx.begin(), hdx.end()), vw(width, 0.0);
             for (int b = 0; b < blocks; ++b)
                 for (int j = 0; j < width; ++j) vw[j] += hp[(size_t)b * width + j];
