@@ -2108,9 +2108,13 @@ __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const Yunet
 // the producer's BN-backward sums -- the same 128 addresses for the whole launch: with 2048 workgroups those 262 k
 // same-address atomics, not the 59 - 370 MB of traffic, set the time (pool_bwd + upadd_bwd 0.260 ms per step).
 // Measured: cap 1024 0.223 ms, 768 0.213, 512 0.216, 384 0.242, 256 0.295 (too few waves in flight).
+// With the sums in eight replicas (YunetBN::slots) the order is the same -- 768 0.209 ms, 1536 0.255, 2048 0.257,
+// 4096 0.302: it is the NUMBER of fp64 atomics of a launch (2 * C per workgroup), not only their addresses.
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 768 ? 768 : b));
+    long long cap = 768;
+    if (const char* e = getenv("YUNET_EW_GRID")) cap = atoll(e) > 0 ? atoll(e) : cap;   // measurement knob
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 }  // namespace

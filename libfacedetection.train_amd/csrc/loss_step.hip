@@ -275,6 +275,10 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
     }
     int dk = (int)sum;  // .int(): truncation toward zero
     dk = dk < 1 ? 1 : dk;
+    // at most TOPK IoUs <= 1 were added, so dk <= TOPK for finite predictions.  A diverged model (inf / NaN boxes)
+    // can make the sum inf and (int)inf = INT_MAX: bound the loop so that a diverged run reports NaN losses, as the
+    // reference does, instead of spinning for 2^31 iterations per (image, GT) pair
+    dk = dk > TOPK ? TOPK : dk;
     for (int k = 0; k < dk; ++k) {
         const unsigned long long key = ((unsigned long long)ord(tc[0]) << 32) | (uint32_t)tv[0];
         const unsigned long long kmin = wave_min_u64(key);
