@@ -271,21 +271,27 @@ def eval_map_single_class(det_results, annotations, iou_thr=0.5):
     return (float(ap) if num_gts > 0 else 0.0), res
 
 
-def prepare_test_image(img_bgr, scale, device):
+def prepare_test_image(img_bgr, scale, device, resize='cv2'):
     """The test pipeline of the shipped configs on the device (configs/yunet_n.py:57-86: MultiScaleFlipAug(
     img_scale, flip=False) -> Resize(keep_ratio=True) -> Normalize(mean 0, std 1) -> Pad(size_divisor 32)):
     uint8 [h, w, 3] -> (float32 [1, 3, H, W] on the device, img_meta).  mmcv.imrescale semantics for the size
-    (factor = min(long / long_edge, short / short_edge), rounded); scale None keeps the original size."""
+    (factor = min(long / long_edge, short / short_edge), rounded); scale None keeps the original size.
+    The image is resized while it is still uint8, as the reference does, in cv2.resize's fixed-point arithmetic
+    (imresize.resize_linear_u8); resize='float' is the fp32 bilinear this function used before (A/B only)."""
     import torch
     import torch.nn.functional as F
+    from . import imresize
     h, w = img_bgr.shape[:2]
-    x = torch.from_numpy(img_bgr).to(device).permute(2, 0, 1)[None].float()
+    x8 = torch.from_numpy(np.ascontiguousarray(img_bgr)).to(device)
     if scale is None:
         nh, nw = h, w
+        x = x8.permute(2, 0, 1)[None].float()
     else:
-        f = min(max(scale) / max(h, w), min(scale) / min(h, w))
-        nw, nh = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
-        x = F.interpolate(x, size=(nh, nw), mode='bilinear', align_corners=False)
+        nw, nh = imresize.rescale_size(w, h, scale)
+        if resize == 'cv2' and x8.dtype == torch.uint8:
+            x = imresize.resize_linear_u8(x8, (nw, nh)).permute(2, 0, 1)[None].float()
+        else:
+            x = F.interpolate(x8.permute(2, 0, 1)[None].float(), size=(nh, nw), mode='bilinear', align_corners=False)
     ph = max(nh, 0 if scale is None else scale[0] if nh <= scale[0] else nh)
     pw = max(nw, 0 if scale is None else scale[1] if nw <= scale[1] else nw)
     ph, pw = (ph + 31) // 32 * 32, (pw + 31) // 32 * 32

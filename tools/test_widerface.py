@@ -4,12 +4,13 @@ tools/test_widerface.py (CONFIG CHECKPOINT [--out DIR] [--save-preds] [--thr T] 
 
     mode 0 (640, 640) | 1 (1100, 1650) | 2 origin size, padded to a multiple of 32 | >30 (mode, mode)
 
-Per image: PIL decode (BGR) -> keep-ratio bilinear resize on the GPU -> zero pad -> eval forward +
-get_bboxes with rescale=True (HIP kernels) -> x y w h score rows -> wider_evaluation (easy / medium /
-hard AP at IoU 0.5).  `--eval-only PRED_DIR` skips inference and scores saved prediction files.
+Per image: PIL decode (BGR) -> keep-ratio resize of the uint8 image on the GPU in cv2.resize's fixed-point
+arithmetic (yunet_amd/imresize.py) -> zero pad -> eval forward + get_bboxes with rescale=True (HIP kernels) ->
+x y w h score rows -> wider_evaluation (easy / medium / hard AP at IoU 0.5).  `--eval-only PRED_DIR` skips
+inference and scores saved prediction files.
 
-Not pinned against the reference: its Resize runs cv2's uint8 fixed-point bilinear on the CPU
-(cv2 is not installed here); this tool resizes in fp32, results can differ in the last grey level.
+The resize restates OpenCV's published algorithm and is tested against a per-pixel restatement of it; cv2 itself
+is not installed here, so the library's own output does not pin it.
 Mode 1 pads 1100 x 1650 up to 1120 x 1664 (the network needs multiples of 32).
 """
 import argparse
