@@ -160,16 +160,19 @@ class RetinaFaceDataset:
 
 
 class RetinaFaceSource:
-    """Training data source over a RetinaFaceDataset: per iteration a deterministic shuffled slice
-    of the epoch (seed, epoch, rank, world -> the DistributedGroupSampler role), decoded with PIL on
-    the host, augmented on the GPU by the config's own pipeline (pipelines.DevicePipeline)."""
+    """Training data source over a RetinaFaceDataset: iteration `it` of rank r is batch it % iters_per_epoch of the
+    reference's DistributedGroupSampler(dataset, samples_per_gpu, world, r, seed) in epoch it // iters_per_epoch
+    (samplers.py; the order `tools/dist_train.sh` feeds, also used at world size 1, where the reference's
+    GroupSampler draws from numpy's global generator and is not reproducible).  Samples are decoded with PIL on
+    the host and augmented on the GPU by the config's own pipeline (pipelines.DevicePipeline)."""
 
     def __init__(self, dataset, pipeline, samples_per_gpu=16, rank=0, world=1, seed=0, max_gt=64, workers=4):
         from .pipelines import DevicePipeline
         self.ds, self.bs, self.rank, self.world, self.seed = dataset, samples_per_gpu, rank, world, seed
         self.pipe = DevicePipeline(pipeline, seed=seed + 7919 * rank, gmax=64 if max_gt <= 64 else 128)
-        per_rank = len(dataset) // world
-        self.iters_per_epoch = max(1, per_rank // samples_per_gpu)
+        from .samplers import DistributedGroupSampler
+        self.sampler = DistributedGroupSampler(dataset, samples_per_gpu, world, rank, seed=seed)
+        self.iters_per_epoch = max(1, len(self.sampler) // samples_per_gpu)
         self._perm_epoch, self._perm = None, None
         # decode ahead: the samples of iteration it + 1 are decoded by a small thread pool (PIL releases
         # the GIL while decoding) while the GPU runs iteration it -- the role of the reference's
@@ -181,12 +184,10 @@ class RetinaFaceSource:
     def _indices(self, it):
         epoch, k = divmod(it, self.iters_per_epoch)
         if self._perm_epoch != epoch:
-            g = torch.Generator().manual_seed(self.seed + epoch)
-            self._perm = torch.randperm(len(self.ds), generator=g).tolist()
+            self.sampler.set_epoch(epoch)
+            self._perm = list(iter(self.sampler))
             self._perm_epoch = epoch
-        per_rank = len(self.ds) // self.world
-        base = self.rank * per_rank + k * self.bs
-        return [self._perm[(base + j) % len(self.ds)] for j in range(self.bs)]
+        return self._perm[k * self.bs:(k + 1) * self.bs]
 
     def _decoded(self, it):
         if self.workers == 0:

@@ -152,9 +152,11 @@ def test_dataset_min_side_filter_exif_and_decode_ahead(tmp_path):
     # decode-ahead == synchronous
     a = DS.RetinaFaceSource.__new__(DS.RetinaFaceSource)
     b = DS.RetinaFaceSource.__new__(DS.RetinaFaceSource)
+    from yunet_amd.samplers import DistributedGroupSampler
     for o, w in ((a, 0), (b, 3)):
         o.ds, o.bs, o.rank, o.world, o.seed = ds, 2, 0, 1, 5
-        o.iters_per_epoch, o._perm_epoch, o._perm = 3, None, None
+        o.sampler = DistributedGroupSampler(ds, 2, 1, 0, seed=5)
+        o.iters_per_epoch, o._perm_epoch, o._perm = len(o.sampler) // 2, None, None
         o.workers, o._pool, o._ahead = w, None, {}
     for it in (0, 1, 2, 3, 4, 7):                                                 # crosses an epoch, then jumps
         sa, sb = a._decoded(it), b._decoded(it)
