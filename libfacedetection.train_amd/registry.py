@@ -5,6 +5,7 @@ python-dict configs (mmdet/models/builder.py:7-15, mmdet/core/bbox/builder.py:4-
 mmdet/core/anchor/builder.py:6-12).  mmcv is un-vendored and not installable here, so the
 same surface is provided natively; only the behaviour the shipped configs use is kept.
 """
+import argparse
 import os
 
 
@@ -55,6 +56,97 @@ class Config(ConfigDict):
                     node[p] = ConfigDict()          # mmcv creates the intermediate dicts (e.g. fp16.loss_scale=512.)
                 node = node[p]
             node[parts[-1]] = value
+
+    @property
+    def pretty_text(self):
+        """The configuration as python source (what mmcv.Config.pretty_text is for: the text the tools log and
+        store in checkpoint meta; mmcv runs its output through a code formatter, so only the CONTENT agrees):
+        one `name = value` statement per top-level key, dicts as dict(...) calls, loadable by Config.fromfile."""
+        def fmt(v, ind):
+            pad = ' ' * (ind + 4)
+            if isinstance(v, dict):
+                if not v:
+                    return 'dict()'
+                if all(isinstance(k, str) and k.isidentifier() for k in v):
+                    body = ''.join(f'{pad}{k}={fmt(x, ind + 4)},\n' for k, x in v.items())
+                    return 'dict(\n' + body + ' ' * ind + ')'
+                body = ''.join(f'{pad}{k!r}: {fmt(x, ind + 4)},\n' for k, x in v.items())
+                return '{\n' + body + ' ' * ind + '}'
+            if isinstance(v, (list, tuple)):
+                o, c = ('[', ']') if isinstance(v, list) else ('(', ')')
+                if not any(isinstance(x, (dict, list, tuple)) for x in v):
+                    inner = ', '.join(fmt(x, ind) for x in v)
+                    return o + inner + (',' if isinstance(v, tuple) and len(v) == 1 else '') + c
+                body = ''.join(f'{pad}{fmt(x, ind + 4)},\n' for x in v)
+                return o + '\n' + body + ' ' * ind + c
+            if isinstance(v, range):
+                return repr(list(v))
+            return repr(v)
+        return ''.join(f'{k} = {fmt(v, 0)}\n' for k, v in self.items() if k != 'filename')
+
+    def dump(self, path=None):
+        """mmcv.Config.dump for python configs: writes pretty_text (tools/train.py:171 stores the run's
+        configuration next to its logs); returns the text when no path is given."""
+        text = self.pretty_text
+        if path is None:
+            return text
+        with open(path, 'w') as f:
+            f.write(text)
+
+
+class DictAction(argparse.Action):
+    """argparse action of `--cfg-options` / `--options` (mmcv.DictAction, used by tools/train.py:66-82 and
+    tools/test_widerface.py): KEY=VALUE pairs -> dict.  A value is an int, a float, true / false (any case), or
+    a string; `a,b`, `[a,b]` give lists and `(a,b)` a tuple, nested to any depth; quotes around the value and
+    blanks inside it are dropped."""
+
+    @staticmethod
+    def _scalar(text):
+        for conv in (int, float):
+            try:
+                return conv(text)
+            except ValueError:
+                pass
+        if text.lower() in ('true', 'false'):
+            return text.lower() == 'true'
+        return text
+
+    @classmethod
+    def parse_value(cls, text):
+        text = text.strip('\'"').replace(' ', '')
+        as_tuple = False
+        if text.startswith('(') and text.endswith(')'):
+            as_tuple, text = True, text[1:-1]
+        elif text.startswith('[') and text.endswith(']'):
+            text = text[1:-1]
+        elif ',' not in text:
+            return cls._scalar(text)
+        items, depth, start = [], 0, 0
+        for i, ch in enumerate(text):
+            if ch in '([':
+                depth += 1
+            elif ch in ')]':
+                depth -= 1
+                if depth < 0:
+                    raise ValueError(f'unbalanced brackets in {text!r}')
+            elif ch == ',' and depth == 0:
+                items.append(text[start:i])
+                start = i + 1
+        if depth != 0:
+            raise ValueError(f'unbalanced brackets in {text!r}')
+        if start < len(text):
+            items.append(text[start:])
+        out = [cls.parse_value(t) for t in items]
+        return tuple(out) if as_tuple else out
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        options = {}
+        for kv in values:
+            if '=' not in kv:
+                raise argparse.ArgumentError(self, f'expected KEY=VALUE, got {kv!r}')
+            key, val = kv.split('=', 1)
+            options[key] = self.parse_value(val)
+        setattr(namespace, self.dest, options)
 
 
 class Registry:

@@ -483,6 +483,35 @@ def find_latest_checkpoint(path, suffix='pth'):
     return best_path
 
 
+def auto_scale_lr(cfg, distributed, log=print):
+    """mmdet/apis/train.py:71-113: the linear scaling rule, applied when the config carries
+    `auto_scale_lr = dict(enable=True, base_batch_size=B)` (tools/train.py --auto-scale-lr switches `enable` on):
+    optimizer.lr *= (GPUs x samples_per_gpu) / B.  Returns the learning rate in effect."""
+    asl = cfg.get('auto_scale_lr')
+    if not asl or not asl.get('enable', False):
+        log('Automatic scaling of learning rate (LR) has been disabled.')
+        return cfg.optimizer['lr']
+    base = asl.get('base_batch_size')
+    if base is None:
+        return cfg.optimizer['lr']
+    if distributed:
+        from .parallel import get_dist_info
+        num_gpus = get_dist_info()[1]
+    else:
+        num_gpus = len(cfg.get('gpu_ids') or [0])
+    data = cfg.get('data') or {}
+    spg = (data.get('train_dataloader') or {}).get('samples_per_gpu', data.get('samples_per_gpu'))
+    batch = num_gpus * spg
+    log(f'Training with {num_gpus} GPU(s) with {spg} samples per GPU. The total batch size is {batch}.')
+    if batch != base:
+        scaled = (batch / base) * cfg.optimizer['lr']
+        log(f"LR has been automatically scaled from {cfg.optimizer['lr']} to {scaled}")
+        cfg.optimizer['lr'] = scaled
+    else:
+        log(f"The batch size match the base batch size: {base}, will not scaling the LR ({cfg.optimizer['lr']}).")
+    return cfg.optimizer['lr']
+
+
 def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None,
                    meta=None, max_iters=None, device='cuda', log=print):
     """mmdet/apis/train.py:117-246 surface: DDP wrap, optimizer, EpochBasedRunner, fp16 / optimizer /
@@ -493,6 +522,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     if distributed:
         model = build_ddp(model, device, device_ids=[torch.cuda.current_device()],
                           broadcast_buffers=False)
+    auto_scale_lr(cfg, distributed, log if cfg.get('auto_scale_lr') else (lambda *a: None))
     optimizer = build_optimizer(model, cfg.optimizer)
     runner = EpochBasedRunner(model, optimizer, cfg.get('work_dir'), log, meta,
                               max_epochs=cfg.runner['max_epochs'], max_iters=max_iters)
