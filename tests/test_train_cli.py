@@ -117,3 +117,17 @@ def test_main_hands_over_to_train_detector(tmp_path, monkeypatch):
     assert kw['meta']['seed'] == 5 and 'YuNet_Head' in kw['meta']['config'] and kw['meta']['exp_name'] == 'yunet_n.py'
     dumped = Config.fromfile(str(tmp_path / 'w' / 'yunet_n.py'))
     assert dumped.data.samples_per_gpu == 4 and dumped.work_dir == str(tmp_path / 'w') and dumped.gpu_ids == [1]
+
+
+def test_no_function_reads_an_undefined_name():
+    """Static check over every python file of the product, the tools, the bench and the oracle: a function that
+    reads a name no scope defines (tools/train.py once passed `a.no_validate` for `args.no_validate`, on a line no
+    test executed) fails here instead of at the user's first run."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'dbg'))
+    import undefined_names as U
+    files = [f for pat in ('libfacedetection.train_amd/*.py', 'tools/*.py', 'tools/dbg/*.py', 'oracle/*.py', '*.py')
+             for f in glob.glob(os.path.join(ROOT, pat))]
+    assert len(files) > 40
+    bad = [(os.path.relpath(f, ROOT),) + b for f in files for b in U.check(f)]
+    assert not bad, bad
