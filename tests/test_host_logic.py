@@ -152,6 +152,50 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
         E.YuNetEngine(O.yunet_arch('n'), 'cpu').get_plan(1, 100, 100, 1)
 
 
+def test_plan_bn_sum_blocks_are_disjoint_replica_tiles():
+    """Layout of the BatchNorm sums (YunetBN::slots): every layer owns one [slots, 2c] forward block and one
+    backward block, the blocks tile the single fp64 buffer the step zeroes with one memset, the descriptors handed
+    to the kernels and the rows of the bn_batch tables point at those blocks with the same replica count."""
+    import ctypes as C
+    import yunet_amd._lib as L
+    import yunet_amd.engine as E
+    eng = E.YuNetEngine(O.yunet_arch('n'), 'cpu')
+    plan = eng.get_plan(2, 320, 320, 3)
+    R = E.BN_SLOTS
+    assert R == 8
+    base, total = plan.stats.data_ptr(), plan.stats.numel()
+    spans = []
+    for name, b in plan.bn.items():
+        for key in ('stats', 'bstats'):
+            v = b[key]
+            assert v.shape == (R, 2 * b['c']) and v.is_contiguous() and v.dtype == torch.float64
+            lo = (v.data_ptr() - base) // 8
+            spans.append((lo, lo + v.numel(), name, key))
+    spans.sort()
+    assert spans[0][0] == 0 and spans[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), 'blocks overlap or leave holes'
+    # the one memset of the step covers the whole buffer
+    ms = plan.ops_memset_stats
+    assert ms.opcode == L.OP_MEMSET and ms.p[0] == base
+    assert (ms.i[0] & 0xffffffff) | (ms.i[1] << 32) == total * 8
+    # descriptors inside the op records
+    blocks = {(b['stats'].data_ptr(), b['bstats'].data_ptr()): b['c'] for b in plan.bn.values()}
+    seen = 0
+    for op in plan.fwd_a + plan.bwd:
+        if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
+            for bn, on in ((op.dp.in_bn, op.dp.in_transform == L.T_BNRELU), (op.dp.out_bn, op.dp.out_has_bn)):
+                if on:
+                    assert (bn.stats, bn.bstats) in blocks and bn.slots == R
+                    seen += 1
+    assert seen > 40
+    # bn_batch tables: offset (in doubles), c, count, ..., slots
+    for tab, which in ((plan.bn_table_f, 'stats'), (plan.bn_table_b, 'bstats')):
+        rows = tab.numpy()
+        assert rows.shape == (len(plan.bn), 7) and (rows[:, 6] == R).all()
+        want = sorted((b[which].data_ptr() - base) // 8 for b in plan.bn.values())
+        assert sorted(rows[:, 0].tolist()) == want
+
+
 def test_lr_schedule_matches_mmcv_semantics():
     """regular lr = 0.01*0.1^(#steps<=epoch); linear warm-up over 1500 iters
     from ratio 0.001; checkpoint optimizer lr after both steps is 1e-4."""
