@@ -20,6 +20,14 @@
 #ifndef YUNET_FWD_SPLIT3
 #define YUNET_FWD_SPLIT3 1
 #endif
+// A/B variant (tools/ubench/build_ab.sh ilv "-DYUNET_FWD_MFMA_INTERLEAVE=1"), OFF by default until it is measured:
+// the six products of the 3-way split issued product-major / output-tile-minor, so that consecutive matrix
+// instructions write DIFFERENT accumulators.  Every accumulator still receives its six products in the same order
+// (small terms first): results are bit-identical.  Motive: in the default order hipcc emits runs of 4-6 matrix
+// instructions into one accumulator (a dependent one issues only when its predecessor has left the pipe).
+#ifndef YUNET_FWD_MFMA_INTERLEAVE
+#define YUNET_FWD_MFMA_INTERLEAVE 0
+#endif
 
 namespace {
 
@@ -418,6 +426,29 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     }
                     const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, ah), Am = __builtin_bit_cast(bf16x8_t, am),
                                    Al = __builtin_bit_cast(bf16x8_t, al);
+#if YUNET_FWD_MFMA_INTERLEAVE
+                    bf16x8_t Bh[G::NT], Bm[G::NT], Bl[G::NT];
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) {
+                        const int co = nt * 16 + l15;
+                        const __bf16* bp = s_w1p + co * CIN + (((4 * kb + g) ^ (co & (NCH - 1))) << 3);
+                        Bh[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp));
+                        Bl[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + 2 * COUT * CIN));
+                        Bm[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + COUT * CIN));
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[nt], acc[nt], 0, 0, 0);
+#else
 #pragma unroll
                     for (int nt = 0; nt < G::NT; ++nt) {
                         const int co = nt * 16 + l15;
@@ -434,6 +465,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
                         acc[nt] = c;
                     }
+#endif
                 }
             } else if constexpr (BF16_MMA) {
                 // lane group g supplies input channels 32*kb + 8g .. +7 on both sides
