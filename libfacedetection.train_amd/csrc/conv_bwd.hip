@@ -1068,6 +1068,29 @@ __device__ __forceinline__ f32x4 mfma3r(const u32x4 ah, const u32x4 al, const u3
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, c, 0, 0, 0);
     return c;
 }
+// A/B variant, OFF by default until measured (tools/ubench/build_ab.sh ilvb "-DYUNET_BWD_MFMA_INTERLEAVE=1"): the
+// same three products for four accumulators issued product-major, so that consecutive matrix instructions write
+// different accumulators; each accumulator receives lo*hi, hi*lo, hi*hi in mfma3r's order (bit-identical results).
+#ifndef YUNET_BWD_MFMA_INTERLEAVE
+#define YUNET_BWD_MFMA_INTERLEAVE 0
+#endif
+#if YUNET_BWD_MFMA_INTERLEAVE
+#define MFMA3R_X4(C0, C1, C2, C3, AH0, AL0, BH0, BL0, AH1, AL1, BH1, BL1, AH2, AL2, BH2, BL2, AH3, AL3, BH3, BL3)        \
+    do {                                                                                                                \
+        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL0), __builtin_bit_cast(bf16x8, BH0), C0, 0, 0, 0); \
+        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL1), __builtin_bit_cast(bf16x8, BH1), C1, 0, 0, 0); \
+        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL2), __builtin_bit_cast(bf16x8, BH2), C2, 0, 0, 0); \
+        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL3), __builtin_bit_cast(bf16x8, BH3), C3, 0, 0, 0); \
+        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH0), __builtin_bit_cast(bf16x8, BL0), C0, 0, 0, 0); \
+        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH1), __builtin_bit_cast(bf16x8, BL1), C1, 0, 0, 0); \
+        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH2), __builtin_bit_cast(bf16x8, BL2), C2, 0, 0, 0); \
+        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH3), __builtin_bit_cast(bf16x8, BL3), C3, 0, 0, 0); \
+        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH0), __builtin_bit_cast(bf16x8, BH0), C0, 0, 0, 0); \
+        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH1), __builtin_bit_cast(bf16x8, BH1), C1, 0, 0, 0); \
+        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH2), __builtin_bit_cast(bf16x8, BH2), C2, 0, 0, 0); \
+        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH3), __builtin_bit_cast(bf16x8, BH3), C3, 0, 0, 0); \
+    } while (0)
+#endif
 }  // namespace bwd64
 
 template <int NW, bool PACKED, bool POOLDY>
@@ -1403,8 +1426,13 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     ah[mi] = *reinterpret_cast<const u32x4*>(ap);
                     al[mi] = *reinterpret_cast<const u32x4*>(ap + PLANE);
                 }
+#if YUNET_BWD_MFMA_INTERLEAVE
+                MFMA3R_X4(acc[0], acc[1], acc[2], acc[3], ah[0], al[0], w1h[kb], w1l[kb], ah[1], al[1], w1h[kb], w1l[kb],
+                          ah[2], al[2], w1h[kb], w1l[kb], ah[3], al[3], w1h[kb], w1l[kb]);
+#else
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             float* pw = s_p + (mh * 64 + 4 * go) * C + nt * 16 + l15o;
@@ -1531,10 +1559,15 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     ah[tI] = u32x4{ah0.x, ah0.y, ah1.x, ah1.y}; al[tI] = u32x4{al0.x, al0.y, al1.x, al1.y};
                     bh[tI] = u32x4{bh0.x, bh0.y, bh1.x, bh1.y}; bl[tI] = u32x4{bl0.x, bl0.y, bl1.x, bl1.y};
                 }
+#if YUNET_BWD_MFMA_INTERLEAVE
+                MFMA3R_X4(gw1[0], gw1[1], gw1[2], gw1[3], ah[0], al[0], bh[0], bl[0], ah[0], al[0], bh[1], bl[1],
+                          ah[1], al[1], bh[0], bl[0], ah[1], al[1], bh[1], bl[1]);
+#else
                 gw1[0] = mfma3r(ah[0], al[0], bh[0], bl[0], gw1[0]);
                 gw1[1] = mfma3r(ah[0], al[0], bh[1], bl[1], gw1[1]);
                 gw1[2] = mfma3r(ah[1], al[1], bh[0], bl[0], gw1[2]);
                 gw1[3] = mfma3r(ah[1], al[1], bh[1], bl[1], gw1[3]);
+#endif
             }
         }
         DP_BWD64_STAMP(3);
@@ -1561,8 +1594,13 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                         ph[mi] = *reinterpret_cast<const u32x4*>(q);
                         pl[mi] = *reinterpret_cast<const u32x4*>(q + PLANE);
                     }
+#if YUNET_BWD_MFMA_INTERLEAVE
+                    MFMA3R_X4(da[0], da[1], da[2], da[3], ph[0], pl[0], wth[kb], wtl[kb], ph[1], pl[1], wth[kb], wtl[kb],
+                              ph[2], pl[2], wth[kb], wtl[kb], ph[3], pl[3], wth[kb], wtl[kb]);
+#else
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) da[mi] = mfma3r(ph[mi], pl[mi], wth[kb], wtl[kb], da[mi]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -65,12 +65,14 @@ for sl in 1 8; do
       | grep -v yardstick | grep -v "max|" >> $OUT/${R}_bwd_ab.log
 done
 #   6b. queued forward-kernel variants (built by tools/ubench/build_ab.sh NAME "FLAGS"; each prints z / BN-sum errors
-#       against the product library next to its time): ilv = -DYUNET_FWD_MFMA_INTERLEAVE=1
+#       against the product library next to its time): ilv = "-DYUNET_FWD_MFMA_INTERLEAVE=1 -DYUNET_BWD_MFMA_INTERLEAVE=1"
 for v in ilv; do
   if [ -f tools/ubench/libyunet_$v.so ]; then
-    echo "== forward variant $v" >> $OUT/${R}_bwd_ab.log
+    echo "== variant $v: forward, then backward (product, variant, product, variant)" >> $OUT/${R}_bwd_ab.log
     SLOTS=8 FWD=1 REPS=500 timeout 200 tools/ubench/bwd_ab.bin libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so \
         libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so >> $OUT/${R}_bwd_ab.log 2>&1
+    SLOTS=8 REPS=500 timeout 200 tools/ubench/bwd_ab.bin libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so \
+        libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so 2>&1 | grep -v "max|" >> $OUT/${R}_bwd_ab.log
   fi
 done
 #   7. per-phase cycle counters of dp_bwd64 (a -DDP_BWD_PROF build made by tools/ubench/build_ab.sh prof "-DDP_BWD_PROF"),
