@@ -25,6 +25,9 @@
 // instructions write DIFFERENT accumulators.  Every accumulator still receives its six products in the same order
 // (small terms first): results are bit-identical.  Motive: in the default order hipcc emits runs of 4-6 matrix
 // instructions into one accumulator (a dependent one issues only when its predecessor has left the pipe).
+#ifndef YUNET_FWD_PK_STAGE
+#define YUNET_FWD_PK_STAGE 0
+#endif
 #ifndef YUNET_FWD_MFMA_INTERLEAVE
 #define YUNET_FWD_MFMA_INTERLEAVE 0
 #endif
@@ -369,10 +372,21 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     // (halo pixels outside the image hold T(0) here; their pointwise output is
                     // forced to zero in the pw epilogue, which is what the depthwise pads with)
                     float4 v = act_unpack(pre[i]);
+#if YUNET_FWD_PK_STAGE
+                    // A/B variant (off by default): the same subtract and fused multiply-add on float2 vectors
+                    // (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per instruction, bit-identical results)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                    lo = __builtin_elementwise_fma(lo - f32x2{cm.x, cm.y}, f32x2{cs.x, cs.y}, f32x2{cb.x, cb.y});
+                    hi = __builtin_elementwise_fma(hi - f32x2{cm.z, cm.w}, f32x2{cs.z, cs.w}, f32x2{cb.z, cb.w});
+                    v.x = fmaxf(lo.x, relu_floor); v.y = fmaxf(lo.y, relu_floor);
+                    v.z = fmaxf(hi.x, relu_floor); v.w = fmaxf(hi.y, relu_floor);
+#else
                     v.x = fmaxf(fmaf(v.x - cm.x, cs.x, cb.x), relu_floor);
                     v.y = fmaxf(fmaf(v.y - cm.y, cs.y, cb.y), relu_floor);
                     v.z = fmaxf(fmaf(v.z - cm.z, cs.z, cb.z), relu_floor);
                     v.w = fmaxf(fmaf(v.w - cm.w, cs.w, cb.w), relu_floor);
+#endif
                     *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
                 }
             }

@@ -65,8 +65,9 @@ for sl in 1 8; do
       | grep -v yardstick | grep -v "max|" >> $OUT/${R}_bwd_ab.log
 done
 #   6b. queued forward-kernel variants (built by tools/ubench/build_ab.sh NAME "FLAGS"; each prints z / BN-sum errors
-#       against the product library next to its time): ilv = "-DYUNET_FWD_MFMA_INTERLEAVE=1 -DYUNET_BWD_MFMA_INTERLEAVE=1"
-for v in ilv; do
+#       against the product library next to its time): ilv = "-DYUNET_FWD_MFMA_INTERLEAVE=1 -DYUNET_BWD_MFMA_INTERLEAVE=1",
+#       pk = "-DYUNET_FWD_PK_STAGE=1"
+for v in ilv pk; do
   if [ -f tools/ubench/libyunet_$v.so ]; then
     echo "== variant $v: forward, then backward (product, variant, product, variant)" >> $OUT/${R}_bwd_ab.log
     SLOTS=8 FWD=1 REPS=500 timeout 200 tools/ubench/bwd_ab.bin libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so \
