@@ -84,3 +84,25 @@ def unpad_gt(boxes, kps, cnt):
     gk = [kps[i, :int(cnt[i])].clone() for i in range(boxes.shape[0])]
     gl = [torch.zeros(int(cnt[i]), dtype=torch.int64) for i in range(boxes.shape[0])]
     return gb, gl, gk
+
+
+def crowded_gt(counts, h, w, seed):
+    """Ragged GT with PRESCRIBED face counts (the labelv2 reader feeds real WIDER lists: p99 178,
+    max 709 faces per image), same box / landmark distributions as synthetic.make_gt."""
+    import math
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = math.log(4.0 * h / 320.0), math.log(160.0 * h / 320.0)
+    gb, gl, gk = [], [], []
+    for g in counts:
+        u = torch.rand(g, 8, generator=gen)
+        bw = torch.exp(lo + (hi - lo) * u[:, 0] * (0.55 if g > 64 else 1.0))   # crowds are small faces
+        bh = bw * (1.0 + 0.4 * u[:, 1])
+        bw, bh = bw.clamp(max=w - 1.0), bh.clamp(max=h - 1.0)
+        x1, y1 = u[:, 2] * (w - bw), u[:, 3] * (h - bh)
+        gb.append(torch.stack([x1, y1, x1 + bw, y1 + bh], 1).float().contiguous())
+        kp = torch.rand(g, 5, 2, generator=gen)
+        vis = (u[:, 4] < 0.7).float()[:, None].expand(g, 5)
+        gk.append(torch.stack([x1[:, None] + kp[..., 0] * bw[:, None], y1[:, None] + kp[..., 1] * bh[:, None], vis],
+                              -1).float().contiguous())
+        gl.append(torch.zeros(g, dtype=torch.int64))
+    return gb, gl, gk
