@@ -14,6 +14,7 @@ per input shape as an array of `YunetOp` and replayed by ONE C call per phase
 
 PyTorch supplies device memory, streams and torch.distributed only.
 """
+import collections
 import ctypes as C
 import math
 import os
@@ -30,6 +31,7 @@ BN_MOMENTUM = 0.1
 # lines and that tail was 4-5 us of a 14-35 us launch.  Eight replicas remove it (tools/ubench/bwd_ab.cpp,
 # DESIGN.md section 7); the readers add the replicas up.
 BN_SLOTS = max(1, int(os.environ.get('YUNET_BN_SLOTS', '8')))
+MAX_PLANS = max(2, int(os.environ.get('YUNET_MAX_PLANS', '16')))     # plans kept per engine (see get_plan)
 LOG_HEAD = 8          # floats in front of the flat gradient: cls, bbox, obj, kps, total, 3 spare
 
 
@@ -700,7 +702,7 @@ class YuNetEngine:
         self.params = FlatParams(self.layout, self.device)
         self.world_size = world_size
         self.process_group = process_group
-        self.plans = {}
+        self.plans = collections.OrderedDict()      # (N, H, W, Gmax, precision) -> Plan, least recently used first
         self.plan = None
         self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
         self.use_lanes = False          # head chains of the coarser levels on executor side streams (Plan.__init__)
@@ -756,12 +758,21 @@ class YuNetEngine:
         while gmax < max_gt:
             gmax *= 2
         key = (n, h, w, gmax, self.precision)
-        if key not in self.plans:
+        plan = self.plans.get(key)
+        if plan is None:
             if h % 32 or w % 32:
                 raise ValueError('input height/width must be multiples of 32 (reference: '
                                  'max_pool2d(2) x4 + nearest x2 upsampling must line up)')
-            self.plans[key] = Plan(self, n, h, w, gmax)
-        return self.plans[key]
+            plan = self.plans[key] = Plan(self, n, h, w, gmax)
+            # a plan owns every activation / gradient buffer of its shape (hundreds of MB for one 1024 x 1408
+            # image).  Training uses one or two shapes; testing at the original image sizes (tools/test_widerface.py
+            # --mode 2) walks through hundreds: keep the most recently used ones, drop the rest (a dropped plan
+            # stays alive while an autograd graph or `eng.plan` still refers to it)
+            while len(self.plans) > MAX_PLANS:
+                self.plans.popitem(last=False)
+        else:
+            self.plans.move_to_end(key)
+        return plan
 
     def _exec(self, arr, what):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

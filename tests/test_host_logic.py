@@ -196,6 +196,20 @@ def test_plan_bn_sum_blocks_are_disjoint_replica_tiles():
         assert sorted(rows[:, 0].tolist()) == want
 
 
+def test_plan_cache_is_bounded_lru(monkeypatch):
+    """get_plan keeps the most recently used shapes (testing at original image sizes walks through hundreds of
+    shapes, each plan owning all buffers of its shape); a dropped plan stays valid for whoever still holds it."""
+    import yunet_amd.engine as E
+    monkeypatch.setattr(E, 'MAX_PLANS', 3)
+    eng = E.YuNetEngine(O.yunet_arch('s'), 'cpu')
+    ps = [eng.get_plan(1, 32 * i, 64, 1) for i in range(1, 6)]
+    assert [k[1] for k in eng.plans] == [96, 128, 160]
+    assert eng.get_plan(1, 96, 64, 1) is ps[2] and [k[1] for k in eng.plans] == [128, 160, 96]     # a hit refreshes
+    again = eng.get_plan(1, 32, 64, 1)
+    assert again is not ps[0] and len(eng.plans) == 3 and ps[0].P == again.P                      # rebuilt, old one intact
+    assert eng.get_plan(1, 32, 64, 100) is not again                                               # Gmax is part of the key
+
+
 def test_lr_schedule_matches_mmcv_semantics():
     """regular lr = 0.01*0.1^(#steps<=epoch); linear warm-up over 1500 iters
     from ratio 0.001; checkpoint optimizer lr after both steps is 1e-4."""
