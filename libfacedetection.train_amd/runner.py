@@ -483,6 +483,28 @@ def find_latest_checkpoint(path, suffix='pth'):
     return best_path
 
 
+def update_data_root(cfg, log=print):
+    """mmdet/utils/misc.py:45-76 (called first thing by tools/train.py:113 and tools/test.py:138): with the
+    environment variable MMDET_DATASETS set, every string under cfg.data that contains cfg.data_root gets that part
+    replaced by the variable's value, and cfg.data_root becomes that value.  Like the reference, nested dicts are
+    walked, lists (pipelines) are not."""
+    dst = os.environ.get('MMDET_DATASETS')
+    if dst is None or cfg.get('data_root') is None or cfg.get('data') is None:
+        return cfg
+    log(f'MMDET_DATASETS has been set to be {dst}.Using {dst} as data root.')
+    src = cfg['data_root']
+
+    def walk(node):
+        for k, v in list(node.items()):
+            if isinstance(v, dict):
+                walk(v)
+            elif isinstance(v, str) and src in v:
+                node[k] = v.replace(src, dst)
+    walk(cfg['data'])
+    cfg['data_root'] = dst
+    return cfg
+
+
 def auto_scale_lr(cfg, distributed, log=print):
     """mmdet/apis/train.py:71-113: the linear scaling rule, applied when the config carries
     `auto_scale_lr = dict(enable=True, base_batch_size=B)` (tools/train.py --auto-scale-lr switches `enable` on):

@@ -131,3 +131,23 @@ def test_no_function_reads_an_undefined_name():
     assert len(files) > 40
     bad = [(os.path.relpath(f, ROOT),) + b for f in files for b in U.check(f)]
     assert not bad, bad
+
+
+def test_mmdet_datasets_relocates_the_data_root(tmp_path, monkeypatch):
+    """tools/train.py:113 update_data_root: MMDET_DATASETS replaces cfg.data_root inside the strings of cfg.data."""
+    (tmp_path / 'c.py').write_text(open(CFG).read() + """
+data_root = 'data/widerface/'
+data = dict(samples_per_gpu=4,
+            train=dict(type='RetinaFaceDataset', ann_file='data/widerface/labelv2/train/labelv2.txt',
+                       img_prefix='data/widerface/WIDER_train/images/', pipeline=[dict(type='X', root='data/widerface/')]),
+            val=dict(ann_file='data/widerface/labelv2/val/labelv2.txt', other='elsewhere/x.txt'))
+""")
+    cfg = T.prepare_config(T.parse_args([str(tmp_path / 'c.py')]))
+    assert cfg.data.train.ann_file == 'data/widerface/labelv2/train/labelv2.txt' and cfg.data_root == 'data/widerface/'
+    monkeypatch.setenv('MMDET_DATASETS', '/mnt/sets/wf/')
+    cfg = T.prepare_config(T.parse_args([str(tmp_path / 'c.py')]))
+    assert cfg.data_root == '/mnt/sets/wf/'
+    assert cfg.data.train.ann_file == '/mnt/sets/wf/labelv2/train/labelv2.txt'
+    assert cfg.data.train.img_prefix == '/mnt/sets/wf/WIDER_train/images/'
+    assert cfg.data.val.ann_file == '/mnt/sets/wf/labelv2/val/labelv2.txt' and cfg.data.val.other == 'elsewhere/x.txt'
+    assert cfg.data.train.pipeline[0]['root'] == 'data/widerface/'           # lists are not walked (as in the reference)

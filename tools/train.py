@@ -65,6 +65,7 @@ def parse_args(argv=None):
 def prepare_config(args):
     """tools/train.py:107-160: config file + command-line overrides -> the configuration of the run."""
     cfg = yunet_amd.Config.fromfile(args.config)
+    R.update_data_root(cfg)                       # MMDET_DATASETS (tools/train.py:112-113)
     if args.cfg_options is not None:
         cfg.merge_from_dict(args.cfg_options)
     if args.auto_scale_lr:
