@@ -35,6 +35,7 @@ def parse_args():
     p.add_argument('--save-preds', action='store_true')
     p.add_argument('--thr', type=float, default=-1.)
     p.add_argument('--mode', type=int, default=0)
+    p.add_argument('--local_rank', '--local-rank', type=int, default=0)      # accepted like the reference's (single process)
     p.add_argument('--gt-path', default=None, help='directory of the wider_*_val.mat files '
                    '(default: <dir of data.test.ann_file>/gt)')
     p.add_argument('--eval-only', default=None, metavar='PRED_DIR')
