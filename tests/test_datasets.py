@@ -162,3 +162,47 @@ def test_dataset_min_side_filter_exif_and_decode_ahead(tmp_path):
         sa, sb = a._decoded(it), b._decoded(it)
         assert [s['filename'] for s in sa] == [s['filename'] for s in sb]
         assert all(np.array_equal(x['img'], y['img']) for x, y in zip(sa, sb))
+
+
+@pytest.mark.skipif(not os.path.exists(LABELS), reason='reference tree not present')
+@pytest.mark.parametrize('seed', range(12))
+def test_random_label_files_match_reference(tmp_path, seed):
+    """Random labelv2 training files -- every row kind (15 landmark values with visible / occluded / missing (-1)
+    points, optional score, single ignore flag), tiny boxes against a random min_size, empty images, repeated image
+    headers -- parsed by this reader and by the UNMODIFIED reference class: same images, same arrays."""
+    import yunet_amd.datasets as DS
+    rng = np.random.default_rng(100 + seed)
+    lines, names = [], []
+    for i in range(int(rng.integers(3, 25))):
+        name = f'{int(rng.integers(0, 60))}--Ev/{int(rng.integers(0, 12))}.jpg' if rng.random() < 0.9 or not names else str(rng.choice(names))
+        names.append(name)
+        lines.append(f'# {name} {int(rng.integers(20, 1500))} {int(rng.integers(20, 1500))}')
+        for _ in range(int(rng.integers(0, 7))):
+            x1, y1 = rng.uniform(0, 900, 2)
+            w, h = rng.uniform(1, 120, 2) if rng.random() < 0.7 else rng.uniform(1, 12, 2)
+            box = '%.2f %.2f %.2f %.2f' % (x1, y1, x1 + w, y1 + h) if rng.random() < 0.5 else '%d %d %d %d' % (x1, y1, x1 + w, y1 + h)
+            kind = rng.random()
+            if kind < 0.6:
+                pts = []
+                missing_all = rng.random() < 0.2
+                for _k in range(5):
+                    if missing_all or rng.random() < 0.15:
+                        pts += ['-1', '-1', '-1']
+                    else:
+                        pts += ['%.3f' % rng.uniform(0, 900), '%.3f' % rng.uniform(0, 900), str(rng.choice(['0.0', '1.0', '0', '1']))]
+                row = box + ' ' + ' '.join(pts) + (' %.2f' % rng.random() if rng.random() < 0.7 else '')
+            else:
+                row = box + ' ' + str(int(rng.integers(0, 2)))
+            lines.append(row)
+    f = tmp_path / 'l.txt'
+    f.write_text('\n'.join(lines) + '\n')
+    min_size = None if rng.random() < 0.3 else int(rng.integers(2, 20))
+    mine = DS.load_labelv2(str(f), min_size=min_size)
+    ref = _ref_instance(str(f), min_size, False)
+    assert [(it['filename'], it['width'], it['height']) for it in mine] == \
+        [(it['filename'], it['width'], it['height']) for it in ref.data_infos]
+    for i in range(len(mine)):
+        x, y = DS.ann_info(mine[i]), ref.get_ann_info(i)
+        assert set(x) == set(y)
+        for k in x:
+            assert x[k].dtype == y[k].dtype and x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), (i, k)
