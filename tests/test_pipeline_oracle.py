@@ -99,3 +99,38 @@ def test_collate_pads_and_truncates():
     gb, gk, cnt = P.collate(res, 64)
     assert cnt.tolist() == [3, 64] and gb.shape == (2, 64, 4) and gk.shape == (2, 64, 5, 3)
     assert gb[0, 3:].sum() == 0 and gb[1].sum() == 64 * 4
+
+
+@pytest.mark.parametrize('seed,iteration,S', [(21, 0, 160), (22, 3, 320), (23, 17, 320), (24, 1, 640), (25, 999, 160)])
+def test_random_batches_match_live_reference(seed, iteration, S):
+    """Beyond the two committed fixtures: random image sizes / face counts / seeds / iterations through the
+    UNMODIFIED reference transforms (random draws redirected to the counter-based generator, as for the fixtures)
+    and through the oracle -- crop window, kept boxes, flip, number of draws, boxes, keypoints and the whole
+    output image identical."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import ref_stub
+    if not ref_stub.available():
+        pytest.skip('reference tree not present')
+    import make_golden_pipeline as MG
+
+    def imresize(img, size, return_scale=False, interpolation='bilinear', out=None, backend=None):
+        h, w = img.shape[:2]
+        r = P.resize_linear(img, size[0])
+        return (r, size[0] / w, size[1] / h) if return_scale else r
+
+    T = ref_stub.load_pipeline_transforms(imresize=imresize, imflip=lambda img, direction='horizontal': np.flip(img, axis=1))
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for _ in range(8):
+        h, w = int(rng.integers(40, 700)), int(rng.integers(40, 900))
+        g = int(rng.choice([1, 2, 5, 17, 40, -1, -3]))
+        shapes.append((h, w, g))
+    imgs, boxes, kps = zip(*[P.synth_image(rng, h, w, g) for h, w, g in shapes])
+    ref = MG.run_reference(T, imgs, boxes, kps, seed, iteration, S)
+    for i, r in enumerate(ref):
+        o = P.augment_image(imgs[i], boxes[i], kps[i], seed, iteration, i, S, np.array(MG.CROP_CHOICE, np.float64))
+        assert (int(o['params'][2]), bool(o['params'][3])) == (int(r['cw']), r['flip']), (i, shapes[i])
+        assert int(o['mask'].sum()) == len(r['boxes'])
+        assert np.array_equal(o['boxes'], r['boxes']) and np.array_equal(o['kps'], r['kps']), (i, shapes[i])
+        assert np.array_equal(o['img'], r['img']), (i, shapes[i])
