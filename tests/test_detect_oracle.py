@@ -49,3 +49,43 @@ def test_nms_known_answers():
     assert D.nms_greedy(torch.tensor([[0, 0, 1, 1], [5, 5, 6, 6]], dtype=torch.float32),
                         torch.tensor([0.5, 0.5]), 0.45).tolist() == [0, 1]
     assert D.nms_greedy(torch.zeros(0, 4), torch.zeros(0), 0.45).numel() == 0
+
+
+@pytest.mark.parametrize('kind,h,w', [('n', 256, 384), ('s', 320, 192), ('n', 640, 640)])
+def test_rectangular_inputs_match_live_reference(kind, h, w):
+    """Beyond the two square fixtures: rectangular inputs through the
+    UNMODIFIED `simple_test` (eval forward, flatten, sigmoid, decode, threshold, bbox2result; NMS = the restated
+    greedy algorithm, as for the fixtures) and through the oracle."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import ref_stub
+    import yunet_oracle as O
+    if not ref_stub.available():
+        pytest.skip('reference tree not present')
+    ns = ref_stub.load_reference()
+    ns.mods['mmdet.models.dense_heads.yunet_head'].batched_nms = D.batched_nms
+    ns.mods['mmdet.models.detectors.yunet'].bbox2result = importlib.import_module('mmdet.core.bbox.transforms').bbox2result
+    model, _ = ref_stub.build_detector(f'yunet_{kind}.py')
+    arch, sd = D.make_state(kind, 5, size=160)          # weights calibrated to fire on the structured images
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    assert arch == O.yunet_arch(kind)
+    # (same host, same torch kernels on both sides: no need to keep the decisions away from their thresholds
+    #  as the committed fixtures do for the GPU's expf)
+    gen = torch.Generator().manual_seed(1000 + h)
+    big = D.structured_images(2, max(h, w), h + w)
+    img = (big[:, :, :h, :w] * 0.8 + torch.rand(2, 3, h, w, generator=gen) * 50).contiguous()
+    flat, sizes = D.eval_flat(img, sd, arch)
+    assert sizes == [(h // s, w // s) for s in arch['strides']]
+    metas = [dict(img_shape=(h, w, 3), scale_factor=np.ones(4, np.float32)) for _ in range(2)]
+    with torch.no_grad():
+        res = model.simple_test(img, metas, rescale=False)
+    got = D.get_bboxes(flat, sizes, arch['strides'], 0.02, 0.45)
+    total = 0
+    for i, (d, _) in enumerate(got):
+        ref = res[i][0]
+        assert d.shape == ref.shape, (i, d.shape, ref.shape)
+        assert np.allclose(d.numpy(), ref, rtol=1e-5, atol=1e-4)
+        total += len(ref)
+    assert total >= 1
