@@ -11,15 +11,15 @@ import yunet_oracle as O
 pytestmark = pytest.mark.skipif(not ref_stub.available(), reason='reference tree not present')
 
 
-@pytest.mark.parametrize('kind,seed', [('n', 11), ('s', 12)])
-def test_full_step_matches_live_reference(kind, seed):
+@pytest.mark.parametrize('kind,seed,h,w', [('n', 11, 320, 320), ('s', 12, 320, 320), ('n', 13, 192, 320), ('s', 14, 160, 96)])
+def test_full_step_matches_live_reference(kind, seed, h, w):
     import yunet_amd.synthetic as S
     model, cfg = ref_stub.build_detector(f'yunet_{kind}.py')
     model.load_state_dict(ref_stub.load_checkpoint_state(f'yunet_{kind}.pth'))
     arch = O.arch_from_model_cfg(ref_stub.load_config(f'yunet_{kind}.py').model)
     assert arch == O.yunet_arch(kind)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    b = S.make_batch(3, 320, 320, seed)
+    b = S.make_batch(3, h, w, seed)
     losses = model.forward_train(b['img'], b['img_metas'], list(b['gt_bboxes']), b['gt_labels'],
                                  list(b['gt_keypointss']))
     sum(losses.values()).backward()
