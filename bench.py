@@ -229,6 +229,11 @@ def live_traffic(kernel, a):
     return int(2 * kib['FETCH_SIZE'] * 1024 + kib['WRITE_SIZE'] * 1024)
 
 
+# the dispatcher options this process started with (include/yunet_hip.h: yunet_set_option reads the same variables once)
+OPTS = {'no_pack': bool(os.environ.get('YUNET_NO_PACK')), 'bwd_fp32mma': bool(os.environ.get('YUNET_BWD_FP32MMA')),
+        'bwd64_nw': int(os.environ.get('YUNET_BWD64_NW') or 0)}
+
+
 def op_name(op, L):
     names = {L.OP_STEM_FWD: 'stem_fwd_kernel', L.OP_STEM_BWD: 'stem_bwd_kernel',
              L.OP_POOL_FWD: 'pool_fwd_kernel', L.OP_POOL_BWD: 'pool_bwd_kernel',
@@ -244,19 +249,19 @@ def op_name(op, L):
         d = op.dp
         big = d.cin == 16 and d.cout == 16 and d.W >= 64 and d.H >= 32
         packed = (d.cin == 64 and d.cout in (64, 16) and d.H <= 20 and d.W <= 20 and d.N >= 4
-                  and not os.environ.get('YUNET_NO_PACK'))
+                  and not OPTS.get('no_pack'))
         kind = 'fwd' if op.opcode == L.OP_DP_FWD else 'bwd'
         # backward: template argument 1 = split-bf16 matrix path (64 -> 64 units), 0 = exact fp32; then
         # true = dy is a pooled gradient + argmax bytes (fused max_pool2d backward)
         gemm = ''
         if kind == 'bwd':
-            if d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA') and not os.environ.get('YUNET_BWD64_R2'):
+            if d.cin == 64 and d.cout == 64 and not OPTS.get('bwd_fp32mma'):
                 # round 3: dp_bwd64_kernel<waves, packed, pooled dy> (csrc/conv_bwd.hip: bwd64_nw) -- 4 waves (8 x 8
                 # tiles, two workgroups per CU) where the width is a multiple of 8 but not of 16, else 8 (8 x 16 tiles)
-                forced = os.environ.get('YUNET_BWD64_NW')
-                nw = int(forced) if forced in ('4', '8') else (4 if (not packed and d.W % 16 != 0 and d.W % 8 == 0) else 8)
+                forced = OPTS.get('bwd64_nw')
+                nw = forced if forced in (4, 8) else (4 if (not packed and d.W % 16 != 0 and d.W % 8 == 0) else 8)
                 return f"dp_bwd64_kernel<{nw},{'true' if packed else 'false'},{'true' if d.pool_idx else 'false'}>"
-            gemm = ',1' if (d.cin == 64 and d.cout == 64 and not os.environ.get('YUNET_BWD_FP32MMA')) else ',0'
+            gemm = ',0'
             gemm += ',true' if d.pool_idx else ',false'
             # last argument: the whole-tile instance (map = exact multiple of the tile, no validity tests)
             th, tw = (16, 32) if big else (8, 16)
@@ -466,6 +471,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     import yunet_amd
+    import yunet_amd._lib as L
     import yunet_amd.synthetic as S
     from yunet_amd.optim import FusedSGD
     from yunet_amd.parallel import YuNetDistributedDataParallel
@@ -607,9 +613,9 @@ def main():
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
     if rank == 0 and world == 1 and a.dtype == 'f32' and not a.no_exact_bwd:
         # the same step with the 64->64 backward GEMMs on the EXACT fp32 matrix instruction
-        # (YUNET_BWD_FP32MMA is read by the C dispatcher at every launch): the number the headline
+        # (the dispatcher option "bwd_fp32mma", include/yunet_hip.h: yunet_set_option): the number the headline
         # would be without the split-bf16 gradient GEMMs
-        os.environ['YUNET_BWD_FP32MMA'] = '1'
+        L.set_option('bwd_fp32mma', 1)
         try:
             for i in range(3):
                 step(i)
@@ -620,10 +626,10 @@ def main():
             torch.cuda.synchronize()
             dte = time.perf_counter() - t1
         finally:
-            del os.environ['YUNET_BWD_FP32MMA']
+            L.set_option('bwd_fp32mma', 0)
         res['exact_fp32_bwd'] = {'ms_per_step': round(1000.0 * dte / a.steps, 3),
                                  'value': round(a.batch * a.steps / dte, 1), 'unit': 'images/sec',
-                                 'what': 'same run, YUNET_BWD_FP32MMA=1: every backward GEMM on v_mfma_f32_16x16x4_f32'}
+                                 'what': 'same run, option bwd_fp32mma=1: every backward GEMM on v_mfma_f32_16x16x4_f32'}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(a.kind, a.size)
         if not a.no_gpu_eager:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 5
+#define YUNET_ABI_VERSION 6
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -360,6 +360,18 @@ int yunet_aug_decide(const int32_t* src_hw, const float* boxes, const float* kps
  * (src + src_off[n], BGR as loaded) to planar fp32 [N,3,S,S]; `params` from yunet_aug_decide. */
 int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t* src_hw,
                      const int32_t* params, const YunetAugCfg* cfg, int N, float* out_img, void* stream);
+
+/* Measurement switches of the dispatchers (ABI 6).  The library reads the environment ONCE, the first time an
+ * option is needed (YUNET_NO_PACK, YUNET_BWD_FP32MMA, YUNET_BWD64_NW, YUNET_EW_GRID, YUNET_DP_FWD_BLOCKS_PER_CU);
+ * after that only this call changes them -- no launch calls getenv.  Names:
+ *   "no_pack"            1: the 20x20 / 10x10 levels on per-image tiles instead of the packed canvas
+ *   "bwd_fp32mma"        1: every backward GEMM on the exact-fp32 matrix instruction (bench.py: exact_fp32_bwd)
+ *   "bwd64_nw"           0 (by shape) | 4 | 8: waves per workgroup of the 64 -> 64 backward kernel
+ *   "ew_grid"            workgroup cap of the element-wise backward kernels (0 restores the default, 768)
+ *   "fwd_blocks_per_cu"  0 (occupancy API) | 1..4: resident forward workgroups per CU
+ * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
+ * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
+int yunet_set_option(const char* name, int value);
 
 int yunet_abi_version(void);
 /* grid size the fused conv kernels are launched with (rows of wgrad_partials). */

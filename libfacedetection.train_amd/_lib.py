@@ -113,6 +113,7 @@ _SIGNATURES = {
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
     'yunet_exec_lanes': (C.c_int, [C.c_int]),
+    'yunet_set_option': (C.c_int, [C.c_char_p, C.c_int]),
 }
 for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
            'yunet_upadd_fwd', 'yunet_upadd_bwd'):
@@ -142,7 +143,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 5:
+    if lib.yunet_abi_version() != 6:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib
@@ -151,3 +152,11 @@ def load():
 def check(rc, what):
     if rc != 0:
         raise YunetHipError(f'{what} failed with status {rc}')
+
+
+def set_option(name, value):
+    """yunet_set_option(): a measurement switch of the C dispatchers (include/yunet_hip.h); returns the previous value."""
+    rc = load().yunet_set_option(name.encode(), int(value))
+    if rc < 0:
+        raise YunetHipError(f'yunet_set_option({name!r}, {value}) rejected')
+    return rc

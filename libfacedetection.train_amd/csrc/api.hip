@@ -1,4 +1,6 @@
 // api.hip -- fused SGD, op-list executor and misc C-ABI entry points of libyunet_hip.so.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -75,6 +77,42 @@ extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum
                        momentum_buf, (long long)n, lr_dev, momentum, weight_decay, grad_scale,
                        first_step);
     return hip_status();
+}
+
+// ---- measurement switches (common.h: YunetOptions) --------------------------------------------------------------
+YunetOptions& yunet_options() {
+    static YunetOptions o = [] {
+        auto env = [](const char* k, int dflt) {
+            const char* e = getenv(k);
+            return e ? atoi(e) : dflt;
+        };
+        YunetOptions v;
+        v.no_pack = getenv("YUNET_NO_PACK") ? 1 : 0;
+        v.bwd_fp32mma = getenv("YUNET_BWD_FP32MMA") ? 1 : 0;
+        v.bwd64_nw = env("YUNET_BWD64_NW", 0);
+        v.ew_grid = env("YUNET_EW_GRID", 768);
+        v.fwd_blocks_per_cu = env("YUNET_DP_FWD_BLOCKS_PER_CU", 0);
+        if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
+        if (v.ew_grid < 1) v.ew_grid = 768;
+        return v;
+    }();
+    return o;
+}
+extern "C" int yunet_set_option(const char* name, int value) {
+    YunetOptions& o = yunet_options();
+    int* slot = nullptr;
+    if (!name) return YUNET_EINVAL;
+    if (!strcmp(name, "no_pack")) slot = &o.no_pack;
+    else if (!strcmp(name, "bwd_fp32mma")) slot = &o.bwd_fp32mma;
+    else if (!strcmp(name, "bwd64_nw")) slot = &o.bwd64_nw;
+    else if (!strcmp(name, "ew_grid")) slot = &o.ew_grid;
+    else if (!strcmp(name, "fwd_blocks_per_cu")) slot = &o.fwd_blocks_per_cu;
+    if (!slot || value < 0) return YUNET_EINVAL;
+    if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;
+    if (slot == &o.ew_grid && value == 0) value = 768;
+    const int prev = *slot;
+    *slot = value;
+    return prev;
 }
 
 // the same conv entry points compiled with bf16 activation storage (conv_fwd.hip / conv_bwd.hip -DYUNET_ACT_BF16)

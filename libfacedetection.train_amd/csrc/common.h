@@ -198,6 +198,19 @@ __device__ __forceinline__ float bnrelu(float x, float mean, float scale, float 
     return fmaxf(fmaf(x - mean, scale, beta), 0.0f);
 }
 
+// Measurement switches of the dispatchers (A/B runs of tools/kbench.py, bench.py's exact-fp32 backward line).
+// One process-wide record, filled from the environment (YUNET_NO_PACK, YUNET_BWD_FP32MMA, YUNET_BWD64_NW,
+// YUNET_EW_GRID, YUNET_DP_FWD_BLOCKS_PER_CU) the first time it is used and changed afterwards only through
+// yunet_set_option() (api.hip): no launch reads the environment.
+struct YunetOptions {
+    int no_pack;             // 1: the 20 x 20 / 10 x 10 levels on per-image tiles instead of the packed canvas
+    int bwd_fp32mma;         // 1: every backward GEMM on the exact-fp32 matrix instruction (64 -> 64 units too)
+    int bwd64_nw;            // 0 = by shape, 4 | 8: waves per workgroup of dp_bwd64
+    int ew_grid;             // workgroup cap of the element-wise backward kernels (default 768)
+    int fwd_blocks_per_cu;   // 0 = occupancy API, 1..4: resident workgroups per CU of dp_fwd
+};
+YunetOptions& yunet_options();
+
 // Small feature maps (the 20x20 / 10x10 pyramid levels) waste most of an 8x16 tile per image.
 // For them the tile grid is laid over a virtual CANVAS on which the images of the batch sit side
 // by side, R per row, one zero gap column / row between neighbours (pitch = size + 1): a tile then
@@ -224,7 +237,7 @@ static inline PackGeom make_pack(int N, int H, int W) {
 // rejects the (absurd for <= 20x20 maps) case of more than 2^30 elements.
 static inline PackGeom dp_pack_geom(int N, int H, int W) {
     PackGeom g = make_pack(N, H, W);
-    if (getenv("YUNET_NO_PACK")) g.on = 0;    // A/B switch (tools/kbench.py)
+    if (yunet_options().no_pack) g.on = 0;    // A/B switch (tools/kbench.py)
     return g;
 }
 // the packed kernels are instantiated for the units that live on the small pyramid levels

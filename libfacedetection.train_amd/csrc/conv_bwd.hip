@@ -979,6 +979,15 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     int grid = tiles < CONV_BLOCKS ? tiles : CONV_BLOCKS;
     if (grid > d->wgrad_blocks) grid = d->wgrad_blocks;
     if (grid < 1) return YUNET_EINVAL;
+    if (grid < d->wgrad_blocks) {
+        // yunet_dp_bwd_blocks() sized the partial buffer for another kernel's grid (the 64 -> 64 units on 8 x 8
+        // tiles, while this launch is their exact-fp32 A/B variant on 8 x 16 tiles): the reduction sums every row,
+        // so the rows no workgroup of this grid writes are zeroed
+        const size_t width = (size_t)COUT * CIN + COUT + (size_t)COUT * 9 + COUT;
+        if (hipMemsetAsync(d->wgrad_partials + (size_t)grid * width, 0, (size_t)(d->wgrad_blocks - grid) * width * 4,
+                           stream) != hipSuccess)
+            return hip_status();
+    }
     hipLaunchKernelGGL((dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY, FULL>), dim3(grid), dim3(BWD_THREADS), G::SMEM,
                        stream, *d, pk);
     return hip_status();
@@ -1068,29 +1077,6 @@ __device__ __forceinline__ f32x4 mfma3r(const u32x4 ah, const u32x4 al, const u3
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, c, 0, 0, 0);
     return c;
 }
-// A/B variant, OFF by default until measured (tools/ubench/build_ab.sh ilvb "-DYUNET_BWD_MFMA_INTERLEAVE=1"): the
-// same three products for four accumulators issued product-major, so that consecutive matrix instructions write
-// different accumulators; each accumulator receives lo*hi, hi*lo, hi*hi in mfma3r's order (bit-identical results).
-#ifndef YUNET_BWD_MFMA_INTERLEAVE
-#define YUNET_BWD_MFMA_INTERLEAVE 0
-#endif
-#if YUNET_BWD_MFMA_INTERLEAVE
-#define MFMA3R_X4(C0, C1, C2, C3, AH0, AL0, BH0, BL0, AH1, AL1, BH1, BL1, AH2, AL2, BH2, BL2, AH3, AL3, BH3, BL3)        \
-    do {                                                                                                                \
-        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL0), __builtin_bit_cast(bf16x8, BH0), C0, 0, 0, 0); \
-        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL1), __builtin_bit_cast(bf16x8, BH1), C1, 0, 0, 0); \
-        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL2), __builtin_bit_cast(bf16x8, BH2), C2, 0, 0, 0); \
-        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AL3), __builtin_bit_cast(bf16x8, BH3), C3, 0, 0, 0); \
-        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH0), __builtin_bit_cast(bf16x8, BL0), C0, 0, 0, 0); \
-        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH1), __builtin_bit_cast(bf16x8, BL1), C1, 0, 0, 0); \
-        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH2), __builtin_bit_cast(bf16x8, BL2), C2, 0, 0, 0); \
-        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH3), __builtin_bit_cast(bf16x8, BL3), C3, 0, 0, 0); \
-        C0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH0), __builtin_bit_cast(bf16x8, BH0), C0, 0, 0, 0); \
-        C1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH1), __builtin_bit_cast(bf16x8, BH1), C1, 0, 0, 0); \
-        C2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH2), __builtin_bit_cast(bf16x8, BH2), C2, 0, 0, 0); \
-        C3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AH3), __builtin_bit_cast(bf16x8, BH3), C3, 0, 0, 0); \
-    } while (0)
-#endif
 }  // namespace bwd64
 
 template <int NW, bool PACKED, bool POOLDY>
@@ -1426,13 +1412,8 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     ah[mi] = *reinterpret_cast<const u32x4*>(ap);
                     al[mi] = *reinterpret_cast<const u32x4*>(ap + PLANE);
                 }
-#if YUNET_BWD_MFMA_INTERLEAVE
-                MFMA3R_X4(acc[0], acc[1], acc[2], acc[3], ah[0], al[0], w1h[kb], w1l[kb], ah[1], al[1], w1h[kb], w1l[kb],
-                          ah[2], al[2], w1h[kb], w1l[kb], ah[3], al[3], w1h[kb], w1l[kb]);
-#else
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             float* pw = s_p + (mh * 64 + 4 * go) * C + nt * 16 + l15o;
@@ -1559,15 +1540,10 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     ah[tI] = u32x4{ah0.x, ah0.y, ah1.x, ah1.y}; al[tI] = u32x4{al0.x, al0.y, al1.x, al1.y};
                     bh[tI] = u32x4{bh0.x, bh0.y, bh1.x, bh1.y}; bl[tI] = u32x4{bl0.x, bl0.y, bl1.x, bl1.y};
                 }
-#if YUNET_BWD_MFMA_INTERLEAVE
-                MFMA3R_X4(gw1[0], gw1[1], gw1[2], gw1[3], ah[0], al[0], bh[0], bl[0], ah[0], al[0], bh[1], bl[1],
-                          ah[1], al[1], bh[0], bl[0], ah[1], al[1], bh[1], bl[1]);
-#else
                 gw1[0] = mfma3r(ah[0], al[0], bh[0], bl[0], gw1[0]);
                 gw1[1] = mfma3r(ah[0], al[0], bh[1], bl[1], gw1[1]);
                 gw1[2] = mfma3r(ah[1], al[1], bh[0], bl[0], gw1[2]);
                 gw1[3] = mfma3r(ah[1], al[1], bh[1], bl[1], gw1[3]);
-#endif
             }
         }
         DP_BWD64_STAMP(3);
@@ -1594,13 +1570,8 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                         ph[mi] = *reinterpret_cast<const u32x4*>(q);
                         pl[mi] = *reinterpret_cast<const u32x4*>(q + PLANE);
                     }
-#if YUNET_BWD_MFMA_INTERLEAVE
-                    MFMA3R_X4(da[0], da[1], da[2], da[3], ph[0], pl[0], wth[kb], wtl[kb], ph[1], pl[1], wth[kb], wtl[kb],
-                              ph[2], pl[2], wth[kb], wtl[kb], ph[3], pl[3], wth[kb], wtl[kb]);
-#else
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) da[mi] = mfma3r(ph[mi], pl[mi], wth[kb], wtl[kb], da[mi]);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -2150,8 +2121,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const Yunet
 // 4096 0.302: it is the NUMBER of fp64 atomics of a launch (2 * C per workgroup), not only their addresses.
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
-    long long cap = 768;
-    if (const char* e = getenv("YUNET_EW_GRID")) cap = atoll(e) > 0 ? atoll(e) : cap;   // measurement knob
+    const long long cap = yunet_options().ew_grid;      // 768 unless a measurement changed it
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
@@ -2166,13 +2136,10 @@ static bool dp_bwd_big_tile(int H, int W, int cin, int cout) {
 // 4 = two independent 256-thread workgroups per CU on 8 x 8 tiles.  Measured (tools/ubench/bwd_ab, N = 256):
 // 80 x 80 0.415 vs 0.429 ms, 40 x 40 0.139 vs 0.126 ms (a 40-wide map fills 8 x 8 tiles exactly, 17 % of every
 // 8 x 16 tile row is padding), packed 20 x 20 / 10 x 10 canvases 0.052 / 0.023 vs 0.055 / 0.028 ms.  So: 8 x 8
-// tiles where the width is a multiple of 8 but not of 16, 8 x 16 otherwise.  YUNET_BWD64_NW=4|8 forces one
-// (A/B runs).  The choice fixes the persistent grid, i.e. the rows of wgrad_partials: read once per process.
+// tiles where the width is a multiple of 8 but not of 16, 8 x 16 otherwise.  The option bwd64_nw = 4 | 8 forces one
+// (A/B runs).  The choice fixes the persistent grid, i.e. the rows of wgrad_partials.
 static int bwd64_nw(int N, int H, int W) {
-    static const int forced = [] {
-        const char* e = getenv("YUNET_BWD64_NW");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = yunet_options().bwd64_nw;
     if (forced == 4 || forced == 8) return forced;
     if (dp_pack_geom(N, H, W).on) return 8;
     return (W % 16 != 0 && W % 8 == 0) ? 4 : 8;
@@ -2220,7 +2187,6 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
                                           : launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
         if (d->cin == 32) return full816 ? launch_dp_bwd<32, 64, 8, 16, false, 0, true, true>(d, s)
                                          : launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
-        if (getenv("YUNET_BWD64_R2")) return launch_dp_bwd<64, 64, 8, 16, false, 1, true>(d, s);
         return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, true>(d, s) : launch_dp_bwd64<8, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
@@ -2228,22 +2194,18 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     if (dp_bwd_big_tile(d->H, d->W, d->cin, d->cout))    // 160x160 / 80x80 levels: bigger tile
         return (d->H % 16 == 0 && d->W % 32 == 0) ? launch_dp_bwd<16, 16, 16, 32, false, 0, false, true>(d, s)
                                                   : launch_dp_bwd<16, 16, 16, 32>(d, s);
-    // 64 -> 64 units: split-bf16 GEMMs (gradients only); YUNET_BWD_FP32MMA=1 keeps the exact-fp32
-    // matrix instruction (A/B measurements, tools/kbench.py)
-    const bool f32mma = getenv("YUNET_BWD_FP32MMA") != nullptr;
-    // YUNET_BWD64_R2=1: the round-2 split-bf16 kernel (template above) instead of dp_bwd64 (A/B runs)
-    const bool r2 = getenv("YUNET_BWD64_R2") != nullptr;
+    // 64 -> 64 units: split-bf16 GEMMs (gradients only); the option bwd_fp32mma keeps the exact-fp32
+    // matrix instruction (bench.py's exact_fp32_bwd line, tools/kbench.py)
+    const bool f32mma = yunet_options().bwd_fp32mma != 0;
     if (dp_use_pack_bwd(d->N, d->H, d->W, d->cin, d->cout)) {           // 20x20 / 10x10 levels: packed canvas
         if (d->cout == 64) {
             if (f32mma) return launch_dp_bwd<64, 64, 8, 16, true>(d, s);
-            if (r2) return launch_dp_bwd<64, 64, 8, 16, true, 1>(d, s);
             return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, true, false>(d, s) : launch_dp_bwd64<8, true, false>(d, s);
         }
         return launch_dp_bwd<64, 16, 8, 16, true>(d, s);
     }
     if (d->cin == 64 && d->cout == 64 && !f32mma)
-        return r2 ? launch_dp_bwd<64, 64, 8, 16, false, 1>(d, s)
-                  : bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, false>(d, s) : launch_dp_bwd64<8, false, false>(d, s);
+        return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, false>(d, s) : launch_dp_bwd64<8, false, false>(d, s);
     if (d->H % 8 == 0 && d->W % 16 == 0) {       // whole-tile maps of the 16-channel stages (80 x 80 in the shipped nets)
         if (d->cin == 16 && d->cout == 64) return launch_dp_bwd<16, 64, 8, 16, false, 0, false, true>(d, s);
         if (d->cin == 16 && d->cout == 32) return launch_dp_bwd<16, 32, 8, 16, false, 0, false, true>(d, s);

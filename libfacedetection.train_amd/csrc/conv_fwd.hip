@@ -20,17 +20,6 @@
 #ifndef YUNET_FWD_SPLIT3
 #define YUNET_FWD_SPLIT3 1
 #endif
-// A/B variant (tools/ubench/build_ab.sh ilv "-DYUNET_FWD_MFMA_INTERLEAVE=1"), OFF by default until it is measured:
-// the six products of the 3-way split issued product-major / output-tile-minor, so that consecutive matrix
-// instructions write DIFFERENT accumulators.  Every accumulator still receives its six products in the same order
-// (small terms first): results are bit-identical.  Motive: in the default order hipcc emits runs of 4-6 matrix
-// instructions into one accumulator (a dependent one issues only when its predecessor has left the pipe).
-#ifndef YUNET_FWD_PK_STAGE
-#define YUNET_FWD_PK_STAGE 0
-#endif
-#ifndef YUNET_FWD_MFMA_INTERLEAVE
-#define YUNET_FWD_MFMA_INTERLEAVE 0
-#endif
 
 namespace {
 
@@ -372,21 +361,10 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     // (halo pixels outside the image hold T(0) here; their pointwise output is
                     // forced to zero in the pw epilogue, which is what the depthwise pads with)
                     float4 v = act_unpack(pre[i]);
-#if YUNET_FWD_PK_STAGE
-                    // A/B variant (off by default): the same subtract and fused multiply-add on float2 vectors
-                    // (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per instruction, bit-identical results)
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-                    lo = __builtin_elementwise_fma(lo - f32x2{cm.x, cm.y}, f32x2{cs.x, cs.y}, f32x2{cb.x, cb.y});
-                    hi = __builtin_elementwise_fma(hi - f32x2{cm.z, cm.w}, f32x2{cs.z, cs.w}, f32x2{cb.z, cb.w});
-                    v.x = fmaxf(lo.x, relu_floor); v.y = fmaxf(lo.y, relu_floor);
-                    v.z = fmaxf(hi.x, relu_floor); v.w = fmaxf(hi.y, relu_floor);
-#else
                     v.x = fmaxf(fmaf(v.x - cm.x, cs.x, cb.x), relu_floor);
                     v.y = fmaxf(fmaf(v.y - cm.y, cs.y, cb.y), relu_floor);
                     v.z = fmaxf(fmaf(v.z - cm.z, cs.z, cb.z), relu_floor);
                     v.w = fmaxf(fmaf(v.w - cm.w, cs.w, cb.w), relu_floor);
-#endif
                     *reinterpret_cast<float4*>(buf + hp * G::LS + lch4 * 4) = v;
                 }
             }
@@ -440,29 +418,6 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     }
                     const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, ah), Am = __builtin_bit_cast(bf16x8_t, am),
                                    Al = __builtin_bit_cast(bf16x8_t, al);
-#if YUNET_FWD_MFMA_INTERLEAVE
-                    bf16x8_t Bh[G::NT], Bm[G::NT], Bl[G::NT];
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) {
-                        const int co = nt * 16 + l15;
-                        const __bf16* bp = s_w1p + co * CIN + (((4 * kb + g) ^ (co & (NCH - 1))) << 3);
-                        Bh[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp));
-                        Bl[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + 2 * COUT * CIN));
-                        Bm[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + COUT * CIN));
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[nt], acc[nt], 0, 0, 0);
-#else
 #pragma unroll
                     for (int nt = 0; nt < G::NT; ++nt) {
                         const int co = nt * 16 + l15;
@@ -479,7 +434,6 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
                         acc[nt] = c;
                     }
-#endif
                 }
             } else if constexpr (BF16_MMA) {
                 // lane group g supplies input channels 32*kb + 8g .. +7 on both sides
@@ -667,279 +621,6 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     }
 }
 
-#ifndef YUNET_ACT_BF16
-// ------------------------------------------------------------------- EXPERIMENTAL, not dispatched by default
-// dp_fwd_ws_kernel: the 64 -> 64 unit (8 x 16 tiles, fp32, plain layout, no fused pool) as ONE 512-thread
-// workgroup per CU whose waves 0-3 PRODUCE tile t + 1 (input transform into LDS, 3-way split-bf16 pointwise GEMM,
-// p written back in place) while waves 4-7 CONSUME tile t (depthwise rows, z stores, BN sums) from the other of
-// two tile buffers: one workgroup barrier per tile instead of three, and the two waves of every SIMD are by
-// construction in different kinds of phases (VALU / LDS-store vs matrix / LDS-read).  A producer wave stages exactly
-// the M tiles it multiplies, so stage -> GEMM needs no workgroup barrier.  Every output is computed by the same
-// instructions in the same order as in dp_fwd_kernel<64,64,8,16,false,false>: z is expected bit-identical, the
-// BN sums too (same per-thread partials, same reduction order).
-// Written at the end of round 3 without GPU time: never run.  Select with YUNET_FWD_WS=1 for the first A/B
-// (tools/ubench/bwd_ab.bin with FWD=1 prints the difference of z and of the sums against the product kernel).
-namespace fwdws {
-constexpr int C = 64, TH = 8, TW = 16, HW_ = TW + 2, HH_ = TH + 2, HP = HW_ * HH_, MT = (HP + 15) / 16, MP = MT * 16;
-constexpr int LS = C + 4, NT = C / 16, NCH = C / 8, C4 = C / 4;
-constexpr size_t BUF_BYTES = (size_t)MP * LS * 4, W1_BYTES = (size_t)3 * C * C * 2;
-constexpr size_t SMEM = 2 * BUF_BYTES + W1_BYTES + (size_t)(9 * C + C + 3 * C) * 4;
-static_assert(MT == 12 && BUF_BYTES >= 256 * 8 * 8, "three M tiles per producer wave; the sum reduction fits a tile buffer");
-}  // namespace fwdws
-
-__global__ __launch_bounds__(512) void dp_fwd_ws_kernel(const YunetDP d) {
-    using namespace fwdws;
-    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* buf0 = reinterpret_cast<float*>(smem_raw);
-    float* buf1 = reinterpret_cast<float*>(smem_raw + BUF_BYTES);
-    __bf16* s_w1p = reinterpret_cast<__bf16*>(smem_raw + 2 * BUF_BYTES);          // planes h | m | l, swizzled chunks
-    float* s_w2 = reinterpret_cast<float*>(smem_raw + 2 * BUF_BYTES + W1_BYTES);   // [9][C]
-    float* s_b2 = s_w2 + 9 * C;
-    float* s_coef = s_b2 + C;                                                      // mean | scale | beta
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wid < 4;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int H = d.H, W = d.W;
-    const bool bn_in = d.in_transform == YUNET_T_BNRELU;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles_img = tiles_x * tiles_y;
-    const int ntiles = d.N * tiles_img;
-    const unsigned xbytes = (unsigned)(H * W * C) * 4u, zbytes = xbytes;
-
-    // producer lane: channel quad l15, rows g + 4r of the M tiles wid, wid + 4, wid + 8
-    act_raw4 pre[12];
-    auto issue = [&](int t) {
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hp = (wid + 4 * j) * 16 + g + 4 * r;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const bool ok = hp < HP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                const unsigned off = ok ? (unsigned)((y * W + x) * C + l15 * 4) * 4u : xbytes;   // past the end: reads 0
-                pre[j * 4 + r] = act_bufld4(r_x, off);
-            }
-    };
-    int t0 = first_tile();
-    if (producer && t0 < ntiles) issue(t0);
-
-    for (int i = tid; i < C * C; i += 512) {
-        const int co = i / C, ci = i % C;
-        const float w = d.w_pw[i];
-        const __bf16 h = (__bf16)w;
-        const float r1 = w - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        const int at = co * C + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
-        s_w1p[at] = h; s_w1p[C * C + at] = m; s_w1p[2 * C * C + at] = l;
-    }
-    for (int i = tid; i < C * 9; i += 512) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
-    for (int i = tid; i < C; i += 512) s_b2[i] = d.b_dw[i];
-    for (int c = tid; c < C; c += 512) {
-        BNCoef k{0.f, 1.f, 0.f, 1.f};
-        if (bn_in) k = bn_coef(d.in_bn, C, c);
-        s_coef[c] = k.mean; s_coef[C + c] = k.scale; s_coef[2 * C + c] = k.beta;
-    }
-    float bias_pw[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bias_pw[nt] = d.b_pw[nt * 16 + l15];
-    const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
-    __syncthreads();
-
-    // ---- producer: tile t (its loads are in `pre`) -> buf: stage, prefetch the tile after next, GEMM, p in place
-    auto produce = [&](int t, float* buf) {
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        {
-            const float4 cm = *reinterpret_cast<const float4*>(s_coef + l15 * 4);
-            const float4 cs = *reinterpret_cast<const float4*>(s_coef + C + l15 * 4);
-            const float4 cb = *reinterpret_cast<const float4*>(s_coef + 2 * C + l15 * 4);
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int hp = (wid + 4 * j) * 16 + g + 4 * r;
-                    float4 v = act_unpack(pre[j * 4 + r]);
-                    v.x = fmaxf(fmaf(v.x - cm.x, cs.x, cb.x), relu_floor);
-                    v.y = fmaxf(fmaf(v.y - cm.y, cs.y, cb.y), relu_floor);
-                    v.z = fmaxf(fmaf(v.z - cm.z, cs.z, cb.z), relu_floor);
-                    v.w = fmaxf(fmaf(v.w - cm.w, cs.w, cb.w), relu_floor);
-                    *reinterpret_cast<float4*>(buf + hp * LS + l15 * 4) = v;
-                }
-        }
-        // rows of this wave's M tiles were written by this wave only: LDS executes one wave's accesses in order;
-        // the fences keep the compiler from moving the GEMM's reads above the stores
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): belt and braces, once per tile
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (t + (int)gridDim.x < ntiles) issue(t + (int)gridDim.x);      // the registers are free again
-#pragma unroll 1
-        for (int j = 0; j < 3; ++j) {
-            const int mt = wid + 4 * j;
-            f32x4 acc[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* arow = buf + (mt * 16 + l15) * LS + 8 * g;
-#pragma unroll
-            for (int kb = 0; kb < C / 32; ++kb) {
-                const float4 x0v = *reinterpret_cast<const float4*>(arow + 32 * kb);
-                const float4 x1v = *reinterpret_cast<const float4*>(arow + 32 * kb + 4);
-                const float xs[8] = {x0v.x, x0v.y, x0v.z, x0v.w, x1v.x, x1v.y, x1v.z, x1v.w};
-                u32x4 ah, am, al;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a0 = xs[2 * q], a1 = xs[2 * q + 1];
-                    const unsigned hb = pack_bf16x2(a0, a1);
-                    const float r0 = a0 - __uint_as_float(hb << 16), r1 = a1 - __uint_as_float(hb & 0xffff0000u);
-                    const unsigned mb = pack_bf16x2(r0, r1);
-                    const unsigned lb = pack_bf16x2(r0 - __uint_as_float(mb << 16), r1 - __uint_as_float(mb & 0xffff0000u));
-                    ah[q] = hb; am[q] = mb; al[q] = lb;
-                }
-                const bf16x8_t Ah = __builtin_bit_cast(bf16x8_t, ah), Am = __builtin_bit_cast(bf16x8_t, am),
-                               Al = __builtin_bit_cast(bf16x8_t, al);
-                bf16x8_t Bh[NT], Bm[NT], Bl[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int co = nt * 16 + l15;
-                    const __bf16* bp = s_w1p + co * C + (((4 * kb + g) ^ (co & (NCH - 1))) << 3);
-                    Bh[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp));
-                    Bl[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + 2 * C * C));
-                    Bm[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(bp + C * C));
-                }
-                // product-major: consecutive matrix instructions write different accumulators; per accumulator
-                // the order is dp_fwd_kernel's (small terms first)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[nt], acc[nt], 0, 0, 0);
-            }
-            // epilogue: bias, ZERO outside the image (the depthwise pads the pointwise output), in place
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hp = mt * 16 + 4 * g + r;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-                const bool in = hp < HP && y >= 0 && y < H && x >= 0 && x < W;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) buf[hp * LS + nt * 16 + l15] = in ? acc[nt][r] + bias_pw[nt] : 0.0f;
-            }
-        }
-    };
-
-    // ---- consumer: depthwise 3 x 3 of tile t from buf, raw z to HBM, BN partial sums
-    const int ctid = tid & 255;
-    const int cq = ctid % C4, dtx = ctid / C4;              // channel quad, tile column; rows 0 .. TH - 1
-    double st[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st[i] = 0.0;
-    auto consume = [&](int t, const float* buf) {
-        const int n = t / tiles_img, rr = t - n * tiles_img;
-        const int y0 = (rr / tiles_x) * TH, x0 = (rr % tiles_x) * TW;
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
-        const float* pbase = buf + dtx * LS + cq * 4;
-        float4 w2[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w2[k] = *reinterpret_cast<const float4*>(s_w2 + k * C + cq * 4);
-        const float4 b2 = *reinterpret_cast<const float4*>(s_b2 + cq * 4);
-        float ts[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ts[i] = 0.0f;
-        float4 rowA[3], rowB[3], rowC[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            rowA[j] = *reinterpret_cast<const float4*>(pbase + (0 * HW_ + j) * LS);
-            rowB[j] = *reinterpret_cast<const float4*>(pbase + (1 * HW_ + j) * LS);
-        }
-#pragma unroll
-        for (int r = 0; r < TH; ++r) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) rowC[j] = *reinterpret_cast<const float4*>(pbase + ((r + 2) * HW_ + j) * LS);
-            float4 o = b2;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                o.x = fmaf(rowA[j].x, w2[j].x, o.x); o.y = fmaf(rowA[j].y, w2[j].y, o.y);
-                o.z = fmaf(rowA[j].z, w2[j].z, o.z); o.w = fmaf(rowA[j].w, w2[j].w, o.w);
-                o.x = fmaf(rowB[j].x, w2[3 + j].x, o.x); o.y = fmaf(rowB[j].y, w2[3 + j].y, o.y);
-                o.z = fmaf(rowB[j].z, w2[3 + j].z, o.z); o.w = fmaf(rowB[j].w, w2[3 + j].w, o.w);
-                o.x = fmaf(rowC[j].x, w2[6 + j].x, o.x); o.y = fmaf(rowC[j].y, w2[6 + j].y, o.y);
-                o.z = fmaf(rowC[j].z, w2[6 + j].z, o.z); o.w = fmaf(rowC[j].w, w2[6 + j].w, o.w);
-            }
-            const int y = y0 + r, x = x0 + dtx;
-            if (y < H && x < W) {
-                const unsigned zoff = (unsigned)((y * W + x) * C + cq * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z, zoff * 4u, 0, 0);
-                ts[0] += o.x; ts[1] += o.y; ts[2] += o.z; ts[3] += o.w;
-                ts[4] = fmaf(o.x, o.x, ts[4]); ts[5] = fmaf(o.y, o.y, ts[5]);
-                ts[6] = fmaf(o.z, o.z, ts[6]); ts[7] = fmaf(o.w, o.w, ts[7]);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { rowA[j] = rowB[j]; rowB[j] = rowC[j]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st[i] += (double)ts[i];
-    };
-
-    // ---- pipeline: one barrier per tile
-    if (producer && t0 < ntiles) produce(t0, buf0);
-    __syncthreads();
-    int it = 0;
-    for (int t = t0; t < ntiles; t += (int)gridDim.x, ++it) {
-        float* cur = (it & 1) ? buf1 : buf0;
-        float* nxt = (it & 1) ? buf0 : buf1;
-        if (producer) {
-            if (t + (int)gridDim.x < ntiles) produce(t + (int)gridDim.x, nxt);
-        } else {
-            consume(t, cur);
-        }
-        __syncthreads();
-    }
-
-    // ---- BN statistics: the consumers' partials through LDS (a tile buffer is free now), one fp64 atomic per channel
-    if (d.out_has_bn) {
-        double* red = reinterpret_cast<double*>(smem_raw);  // [256][8]
-        if (!producer) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) red[ctid * 8 + i] = st[i];
-        }
-        __syncthreads();
-        if (tid < 2 * C) {
-            const int which = tid / C, c = tid % C;
-            const int q = c >> 2, k = (c & 3) + 4 * which;
-            double v = 0.0;
-            for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + k];
-            atomic_add_f64(bn_slot(d.out_bn.stats, d.out_bn.slots, C) + which * C + c, v);
-        }
-    }
-}
-
-int launch_dp_fwd_ws(const YunetDP* d, hipStream_t stream) {
-    static bool ready = false;
-    const void* fn = reinterpret_cast<const void*>(dp_fwd_ws_kernel);
-    if (!ready) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwdws::SMEM) != hipSuccess) return YUNET_EINVAL;
-        ready = true;
-    }
-    const int tiles = d->N * ((d->W + fwdws::TW - 1) / fwdws::TW) * ((d->H + fwdws::TH - 1) / fwdws::TH);
-    const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU (132 KB of LDS), persistent
-    hipLaunchKernelGGL(dp_fwd_ws_kernel, dim3(grid), dim3(512), fwdws::SMEM, stream, *d);
-    return hip_status();
-}
-#endif  // !YUNET_ACT_BF16
-
 template <int CIN, int COUT, int TH, int TW, bool PACKED = false, bool POOL = false>
 int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
     using G = DpGeom<CIN, COUT, TH, TW>;
@@ -951,8 +632,8 @@ int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
             nb = 1;
         blocks_per_cu = nb > 4 ? 4 : nb;
-        if (const char* e = getenv("YUNET_DP_FWD_BLOCKS_PER_CU"))   // occupancy experiments only
-            if (atoi(e) >= 1 && atoi(e) <= blocks_per_cu) blocks_per_cu = atoi(e);
+        const int forced = yunet_options().fwd_blocks_per_cu;       // occupancy experiments only
+        if (forced >= 1 && forced <= blocks_per_cu) blocks_per_cu = forced;
     }
     // persistent grid: exactly the resident workgroups, so every one pipelines many tiles
     PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
@@ -1083,10 +764,6 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
         return launch_dp_fwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
     if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout))                 // 20x20 / 10x10 levels: packed canvas
         return d->cout == 64 ? launch_dp_fwd<64, 64, 8, 16, true>(d, s) : launch_dp_fwd<64, 16, 8, 16, true>(d, s);
-#ifndef YUNET_ACT_BF16
-    // experimental producer / consumer kernel of the plain 64 -> 64 unit (never run yet, see dp_fwd_ws_kernel)
-    if (d->cin == 64 && d->cout == 64 && !d->prof && getenv("YUNET_FWD_WS")) return launch_dp_fwd_ws(d, s);
-#endif
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

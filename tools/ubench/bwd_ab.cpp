@@ -185,6 +185,15 @@ int main(int argc, char** argv) {
                 d.w_pw = dwp; d.b_pw = dbp; d.w_dw = dwd; d.b_dw = dbd;
                 d.z = dzo;
                 d.out_bn = YunetBN{dst, nullptr, dgo, dbo, (int32_t)px, 1e-5f, slots};
+                // forward: ABL=<mask> (1 skip pointwise GEMM, 2 skip depthwise, 4 skip z stores, 8 skip next-tile loads),
+                // PROF=1 per-phase clocks (stage | pw | dw | barrier) summed over a workgroup's tiles, per wave
+                unsigned long long* fprof = nullptr;
+                if (getenv("ABL")) d.prof = (unsigned long long*)(uintptr_t)atoll(getenv("ABL"));
+                if (getenv("PROF")) {
+                    CK(hipMalloc(&fprof, (size_t)2048 * 8 * 4 * 8));
+                    CK(hipMemset(fprof, 0, (size_t)2048 * 8 * 4 * 8));
+                    d.prof = fprof;
+                }
                 CK(hipMemsetAsync(dst, 0, 2 * co * 8 * slots, st));
                 int rc = v.fwd(&d, st);
                 CK(hipStreamSynchronize(st));
@@ -210,6 +219,25 @@ int main(int argc, char** argv) {
                 } else {
                     printf("%dx%d %d->%d N=%d  fwd %-40s %8.4f ms %7.1f GB/s  err z %.2e stats %.2e\n", H, W, ci, co, N,
                            v.name.c_str(), ms, gbs, rel(vz, rz, 0, vz.size()), rel(hs, rs, 0, hs.size()));
+                }
+                if (fprof) {
+                    CK(hipMemset(fprof, 0, (size_t)2048 * 8 * 4 * 8));
+                    v.fwd(&d, st);
+                    CK(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> hp2((size_t)2048 * 8 * 4);
+                    CK(hipMemcpy(hp2.data(), fprof, hp2.size() * 8, hipMemcpyDeviceToHost));
+                    double acc[4] = {0, 0, 0, 0};
+                    int rows = 0;
+                    for (size_t r = 0; r < hp2.size() / 4; ++r) {
+                        if (!hp2[r * 4] && !hp2[r * 4 + 1]) continue;
+                        ++rows;
+                        for (int k = 0; k < 4; ++k) acc[k] += (double)hp2[r * 4 + k];
+                    }
+                    if (rows)
+                        printf("    fwd clocks per wave (mean over %d waves): stage %.0f | pw %.0f | dw %.0f | barrier %.0f | total %.0f\n",
+                               rows, acc[0] / rows, acc[1] / rows, acc[2] / rows, acc[3] / rows,
+                               (acc[0] + acc[1] + acc[2] + acc[3]) / rows);
+                    CK(hipFree(fprof));
                 }
                 if (!v.env_k.empty()) unsetenv(v.env_k.c_str());
             }
