@@ -208,6 +208,8 @@ struct YunetOptions {
     int bwd64_nw;            // 0 = by shape, 4 | 8: waves per workgroup of dp_bwd64
     int ew_grid;             // workgroup cap of the element-wise backward kernels (default 768)
     int fwd_blocks_per_cu;   // 0 = occupancy API, 1..4: resident workgroups per CU of dp_fwd
+    int fwd64s;              // 1: the plain 64 -> 64 forward unit on the wave-streaming kernel (conv_fwd64.hip)
+    int fwd64s_rows;         // 0 = by shape, else rows per band of that kernel
 };
 YunetOptions& yunet_options();
 
@@ -268,3 +270,6 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 }
 
 static inline int hip_status() { return -(int)hipGetLastError(); }
+
+// conv_fwd64.hip: the plain fp32 64 -> 64 forward unit (no packing, no fused pooling)
+int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream);

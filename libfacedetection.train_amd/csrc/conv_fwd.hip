@@ -764,6 +764,14 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
         return launch_dp_fwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
     if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout))                 // 20x20 / 10x10 levels: packed canvas
         return d->cout == 64 ? launch_dp_fwd<64, 64, 8, 16, true>(d, s) : launch_dp_fwd<64, 16, 8, 16, true>(d, s);
+#ifndef YUNET_ACT_BF16
+    // the plain 64 -> 64 unit: wave-streaming kernel (conv_fwd64.hip); the phase-clock debug mode stays on the
+    // tile kernel
+    #ifdef F64S_PROF
+    if (d->cin == 64 && d->cout == 64 && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
+#endif
+    if (d->cin == 64 && d->cout == 64 && (unsigned long long)d->prof < 64ull && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
+#endif
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

@@ -9,13 +9,14 @@ CSRC=$ROOT/libfacedetection.train_amd/csrc
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
 make -C $CSRC -j8 >/dev/null
-$HIPCC --offload-arch=gfx950 -O2 $ROOT/tools/ubench/bwd_ab.cpp -o $ROOT/tools/ubench/bwd_ab.bin -ldl
+$HIPCC --offload-arch=gfx950 -O2 -Wno-unused-value $ROOT/tools/ubench/bwd_ab.cpp -o $ROOT/tools/ubench/bwd_ab.bin -ldl 2>/dev/null
 while [ $# -ge 2 ]; do
   name=$1; extra=$2; shift 2
   $HIPCC $FLAGS $extra -c $CSRC/conv_bwd.hip -o /tmp/conv_bwd_$name.o &
   $HIPCC $FLAGS $extra -c $CSRC/conv_fwd.hip -o /tmp/conv_fwd_$name.o &
+  $HIPCC $FLAGS $extra -c $CSRC/conv_fwd64.hip -o /tmp/conv_fwd64_$name.o &
   wait
-  $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o /tmp/conv_fwd_$name.o /tmp/conv_bwd_$name.o \
+  $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o /tmp/conv_fwd_$name.o /tmp/conv_fwd64_$name.o /tmp/conv_bwd_$name.o \
       $CSRC/conv_fwd_bf16.o $CSRC/conv_bwd_bf16.o $CSRC/augment.o $CSRC/detect.o $CSRC/api.o \
       -o $ROOT/tools/ubench/libyunet_$name.so
   echo built libyunet_$name.so
