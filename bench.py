@@ -271,9 +271,9 @@ def op_name(op, L):
             gemm += ',true' if full else ',false'
         else:
             # round 4: the plain fp32 64 -> 64 forward unit runs on the wave-streaming kernel (csrc/conv_fwd64.hip)
-            if (d.cin == 64 and d.cout == 64 and not packed and not d.pool_out and d.x_dtype == L.F32
+            if (d.cin == 64 and d.cout == 64 and not packed and d.x_dtype == L.F32
                     and os.environ.get('YUNET_FWD64S', '1') != '0'):
-                return 'dp_fwd64s_kernel'
+                return 'dp_fwd64s_kernel<true>' if d.pool_out else 'dp_fwd64s_kernel<false>'
             gemm = ',true' if d.pool_out else ',false'      # forward: fused pooling outputs
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"
                 f"{'true' if packed and not big else 'false'}{gemm}>")

@@ -138,6 +138,25 @@ __device__ __forceinline__ BNCoef bn_coef(const YunetBN& bn, int C, int c) {
     k.beta = bn.beta[c];
     return k;
 }
+// The element-wise kernels (pool / upsample-add) derive the coefficients ONCE per workgroup: thread c < C computes
+// channel c into an LDS table [5][C] (mean | scale | beta | invstd | mean_lo) and every thread picks up its four
+// channels after the barrier.  (Per thread -- 4 or 8 bn_coef() calls of 16 loads + fp64 sqrt / divide each, in
+// every one of up to 4096 workgroups -- the prologue cost more than the streaming: upadd_fwd ran at 1.4 TB/s.)
+__device__ __forceinline__ void bn_table_fill(float* tab, const YunetBN& bn, int C, int tid) {
+    if (tid < C) {
+        const BNCoef k = bn_coef(bn, C, tid);
+        tab[tid] = k.mean; tab[C + tid] = k.scale; tab[2 * C + tid] = k.beta; tab[3 * C + tid] = k.invstd;
+        tab[4 * C + tid] = k.mean_lo;
+    }
+}
+__device__ __forceinline__ void bn_table_get(const float* tab, int C, int c0, BNCoef (&k)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k[i].mean = tab[c0 + i]; k[i].scale = tab[C + c0 + i]; k[i].beta = tab[2 * C + c0 + i];
+        k[i].invstd = tab[3 * C + c0 + i]; k[i].mean_lo = tab[4 * C + c0 + i];
+    }
+}
+
 // backward constants: dz = k1 * (dy - c1 - xhat * c2), xhat = (z - mean) * invstd
 struct BNBwd {
     float mean, invstd, k1, c1, c2;

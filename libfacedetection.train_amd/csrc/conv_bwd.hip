@@ -1906,9 +1906,11 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const act_t* __restrict__
     const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
     const long long total = (long long)N * Ho * Wo * C4;
     const int c4 = threadIdx.x % C4;
+    __shared__ float s_tab[5 * 64];
+    bn_table_fill(s_tab, bn, C, threadIdx.x);
+    __syncthreads();
     BNCoef k[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] = bn_coef(bn, C, c4 * 4 + i);
+    bn_table_get(s_tab, C, c4 * 4, k);
     double bst[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bst[i] = 0.0;
@@ -1978,12 +1980,13 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
     const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
     const long long total = (long long)N * Hb * Wb * C4;
     const int c4 = threadIdx.x % C4;
+    __shared__ float s_ta[5 * 64], s_tb[5 * 64];
+    bn_table_fill(s_ta, bna, C, threadIdx.x);
+    bn_table_fill(s_tb, bnb, C, threadIdx.x);
+    __syncthreads();
     BNCoef ka[4], kb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ka[i] = bn_coef(bna, C, c4 * 4 + i);
-        kb[i] = bn_coef(bnb, C, c4 * 4 + i);
-    }
+    bn_table_get(s_ta, C, c4 * 4, ka);
+    bn_table_get(s_tb, C, c4 * 4, kb);
     double bsa[8], bsb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsa[i] = bsb[i] = 0.0;
@@ -2237,7 +2240,7 @@ extern "C" int ACT_SUFFIX(yunet_stem_bwd)(const float* img, const float* z, cons
 
 extern "C" int ACT_SUFFIX(yunet_pool_bwd)(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
                                           int accumulate, int N, int H, int W, int C, void* stream) {
-    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const act_t*>(z), *bn, dy_out, dx, accumulate, N, H, W, C);
@@ -2248,7 +2251,7 @@ extern "C" int ACT_SUFFIX(yunet_upadd_bwd)(const float* za, const YunetBN* bna, 
                                            const YunetBN* bnb, const float* dout, float* dxa, int accumulate_a,
                                            float* dxb, int accumulate_b, int N, int H, int W, int C,
                                            void* stream) {
-    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || 2 * C > 256) return YUNET_EINVAL;
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const act_t*>(za), *bna, reinterpret_cast<const act_t*>(zb), *bnb, dout, dxa,

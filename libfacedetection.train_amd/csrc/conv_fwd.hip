@@ -656,9 +656,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const act_t* __restrict__
     const long long total = (long long)N * Ho * Wo * C4;
     // 256 % C4 == 0, so the channel quad of a thread is loop-invariant
     const int c4 = threadIdx.x % C4;
+    __shared__ float s_tab[5 * 64];
+    bn_table_fill(s_tab, bn, C, threadIdx.x);
+    __syncthreads();
     BNCoef k[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] = bn_coef(bn, C, c4 * 4 + i);
+    bn_table_get(s_tab, C, c4 * 4, k);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
          e += (long long)gridDim.x * 256) {
         long long pix = e / C4;
@@ -687,12 +689,13 @@ __global__ __launch_bounds__(256) void upadd_fwd_kernel(const act_t* __restrict_
     const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
     const long long total = (long long)N * H * W * C4;
     const int c4 = threadIdx.x % C4;
+    __shared__ float s_ta[5 * 64], s_tb[5 * 64];
+    bn_table_fill(s_ta, bna, C, threadIdx.x);
+    bn_table_fill(s_tb, bnb, C, threadIdx.x);
+    __syncthreads();
     BNCoef ka[4], kb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ka[i] = bn_coef(bna, C, c4 * 4 + i);
-        kb[i] = bn_coef(bnb, C, c4 * 4 + i);
-    }
+    bn_table_get(s_ta, C, c4 * 4, ka);
+    bn_table_get(s_tb, C, c4 * 4, kb);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
          e += (long long)gridDim.x * 256) {
         long long pix = e / C4;
@@ -726,9 +729,10 @@ __global__ void bn_running_kernel(const double* __restrict__ stats, float* __res
 }
 #endif
 
+// persistent grid of the element-wise forward kernels: 8 workgroups of 256 per CU, grid-stride loops
 inline int ew_grid(long long total) {
     long long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 }  // namespace
@@ -756,6 +760,9 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
             return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_fwd<16, 16, 16, 32, false, true>(d, s);
         if (d->cin == 32) return launch_dp_fwd<32, 64, 8, 16, false, true>(d, s);
+#ifndef YUNET_ACT_BF16
+        if ((unsigned long long)d->prof < 64ull && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
+#endif
         return launch_dp_fwd<64, 64, 8, 16, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
@@ -785,7 +792,7 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
 
 extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
                                           int C, void* stream) {
-    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const act_t*>(z), *bn, reinterpret_cast<act_t*>(out), N, H, W, C);
@@ -795,7 +802,7 @@ extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, flo
 extern "C" int ACT_SUFFIX(yunet_upadd_fwd)(const float* za, const YunetBN* bna, const float* zb,
                                            const YunetBN* bnb, float* out, int N, int H, int W, int C,
                                            void* stream) {
-    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4))) return YUNET_EINVAL;
+    if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * H * W * (C / 4);
     hipLaunchKernelGGL(upadd_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const act_t*>(za), *bna, reinterpret_cast<const act_t*>(zb), *bnb,

@@ -56,7 +56,12 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-__global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_kernel(const YunetDP d, const int R) {
+// POOL (YunetDP.pool_out): besides z, the raw winner of every 2 x 2 window after BN + ReLU and its window position
+// (conv_fwd.hip: dp_fwd_kernel<..., POOL> -- the same rule: maximum for gamma > 0, minimum for gamma < 0, first element
+// for gamma == 0, ties to the smaller position).  A lane owns column PAIRS, so a window needs no cross-lane step: the
+// even row of a pair waits in registers for the odd one (16 more registers: this instance runs two waves per SIMD).
+template <bool POOL>
+__global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(const YunetDP d, const int R) {
     using namespace f64s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* s_w1p = reinterpret_cast<__bf16*>(smem);
@@ -103,6 +108,14 @@ __global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_kernel(const YunetDP 
     __syncthreads();
 
     const float relu_floor = bn_in ? 0.0f : -__builtin_inff();
+    float sg[4] = {1.f, 1.f, 1.f, 1.f};      // fused pooling: which raw value wins a window after BN + ReLU
+    if constexpr (POOL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float gm = d.out_bn.gamma[(lane & 15) * 4 + i];
+            sg[i] = gm > 0.0f ? 1.0f : (gm < 0.0f ? -1.0f : 0.0f);
+        }
+    }
     // prof < 64 is a debug ablation mask (tools/ubench: ABL), not a pointer: 1 skip the matrix instructions,
     // 2 skip the depthwise phase, 4 skip the z stores, 8 skip the input loads (results are then wrong)
 #ifdef F64S_PROF
@@ -130,15 +143,30 @@ __global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_kernel(const YunetDP 
         const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, xbytes, 0x00020000);
         const unsigned xlane = colv ? (unsigned)(col * C + 8 * g) * 4u : xbytes;       // out of the image: reads 0
         const float* biasp = s_b1 + (colv ? C : 0) + 4 * g;
-        // depthwise columns of this lane (strip-local c = cgrp + 4 j), their store offsets and masks
+        // depthwise columns of this lane: two adjacent pairs, strip-local c = 2 cgrp + 8 (j >> 1) + (j & 1); their store
+        // offsets and masks (a pair shares two of its three input columns: 8 LDS reads per row instead of 12)
         unsigned zlane[4];
         float fm[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = cgrp + 4 * j, xc = xs + c;
+            const int c = 2 * cgrp + 8 * (j >> 1) + (j & 1), xc = xs + c;
             const bool v = c < TW && xc < W;
             zlane[j] = v ? (unsigned)(xc * C + cq * 4) * 4u : xbytes;     // dropped by the range check
             fm[j] = v ? 1.0f : 0.0f;
+        }
+        // fused pooling: window (row pair, column pair q) of this lane -> element offset in pool_out / pool_idx
+        const unsigned pobytes = (unsigned)((H >> 1) * (W >> 1) * C) * 4u;
+        const auto r_po = __builtin_amdgcn_make_buffer_rsrc(d.pool_out + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0,
+                                                            POOL ? pobytes : 0u, 0x00020000);
+        const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0,
+                                                            POOL ? pobytes / 4 : 0u, 0x00020000);
+        unsigned plane[2] = {0, 0};
+        if constexpr (POOL) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * cgrp + 8 * q, xc = xs + c;
+                plane[q] = (c < TW && xc < W) ? (unsigned)((xc >> 1) * C + cq * 4) : pobytes;     // elements; dropped when out of range
+            }
         }
         const int rs = y0 > 0 ? y0 - 1 : 0, re = y1 < H ? y1 : H - 1;
         u32x4 xr[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
@@ -158,6 +186,53 @@ __global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_kernel(const YunetDP 
         float ts[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ts[i] = 0.0f;
+
+        // a finished output row: z to HBM, BN partial sums, fused pooling
+        float4 prev[4];
+        auto emit_row = [&](int yy, const float4 (&dn)[4]) {
+            const unsigned zrow = (unsigned)(yy * W * C) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!(abl & 4))
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&dn[j]), r_z, zrow + zlane[j], 0, 0);
+                const float m = fm[j];
+                const float vx = dn[j].x * m, vy = dn[j].y * m, vz = dn[j].z * m, vw = dn[j].w * m;
+                ts[0] += vx; ts[1] += vy; ts[2] += vz; ts[3] += vw;
+                ts[4] = fmaf(vx, vx, ts[4]); ts[5] = fmaf(vy, vy, ts[5]);
+                ts[6] = fmaf(vz, vz, ts[6]); ts[7] = fmaf(vw, vw, ts[7]);
+            }
+            if constexpr (POOL) {
+                if ((yy & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) prev[j] = dn[j];
+                } else {
+                    const unsigned prow = (unsigned)((yy >> 1) * (W >> 1) * C);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float tl[4] = {prev[2 * q].x, prev[2 * q].y, prev[2 * q].z, prev[2 * q].w};
+                        const float bl[4] = {dn[2 * q].x, dn[2 * q].y, dn[2 * q].z, dn[2 * q].w};
+                        const float tr[4] = {prev[2 * q + 1].x, prev[2 * q + 1].y, prev[2 * q + 1].z, prev[2 * q + 1].w};
+                        const float br[4] = {dn[2 * q + 1].x, dn[2 * q + 1].y, dn[2 * q + 1].z, dn[2 * q + 1].w};
+                        float v[4];
+                        unsigned jw = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool lowl = bl[i] * sg[i] > tl[i] * sg[i], lowr = br[i] * sg[i] > tr[i] * sg[i];
+                            const float vl = lowl ? bl[i] : tl[i], vr = lowr ? br[i] : tr[i];
+                            const unsigned jl = lowl ? 2u : 0u, jr = lowr ? 3u : 1u;
+                            const float kl = vl * sg[i], kr = vr * sg[i];
+                            const bool right = kr > kl || (kr == kl && jr < jl);
+                            v[i] = right ? vr : vl;
+                            jw |= (right ? jr : jl) << (8 * i);
+                        }
+                        const unsigned eq = plane[q] == pobytes ? pobytes : prow + plane[q];
+                        const float4 pvv = make_float4(v[0], v[1], v[2], v[3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&pvv), r_po, eq * 4u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(jw, r_pi, eq, 0, 0);
+                    }
+                }
+            }
+        };
 
 #pragma unroll 1
         for (int r = rs; r <= re; ++r) {
@@ -246,51 +321,35 @@ __global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_kernel(const YunetDP 
             // ---- depthwise, accumulate form: this row is the bottom tap row of output row r - 1 (now complete), the
             //      middle of r, the top of r + 1
             if (abl & 2) continue;
-            const bool emit = r - 1 >= y0;
-            const unsigned zrow = (unsigned)((r - 1) * W * C) * 4u;
             float4 w[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(s_w2 + k * C + cq * 4);
+            float4 dn[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* pp = pslot + (cgrp + 4 * j) * LS + cq * 4;
-                const float4 pl = *reinterpret_cast<const float4*>(pp);
-                const float4 pm = *reinterpret_cast<const float4*>(pp + LS);
-                const float4 pr = *reinterpret_cast<const float4*>(pp + 2 * LS);
-                float4 dn = oa[j], mid = ob[j], top = b2;
+            for (int q = 0; q < 2; ++q) {
+                const float* pp = pslot + (2 * cgrp + 8 * q) * LS + cq * 4;
+                float4 pv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pv[k] = *reinterpret_cast<const float4*>(pp + k * LS);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * q + h;
+                    const float4 pl = pv[h], pm = pv[h + 1], pr = pv[h + 2];
+                    float4 o = oa[j], mid = ob[j], top = b2;
 #define TAP(o, k, v)                                                                        \
     o.x = fmaf(v.x, w[k].x, o.x); o.y = fmaf(v.y, w[k].y, o.y); o.z = fmaf(v.z, w[k].z, o.z); \
     o.w = fmaf(v.w, w[k].w, o.w);
-                TAP(dn, 6, pl) TAP(dn, 7, pm) TAP(dn, 8, pr)
-                TAP(mid, 3, pl) TAP(mid, 4, pm) TAP(mid, 5, pr)
-                TAP(top, 0, pl) TAP(top, 1, pm) TAP(top, 2, pr)
+                    TAP(o, 6, pl) TAP(o, 7, pm) TAP(o, 8, pr)
+                    TAP(mid, 3, pl) TAP(mid, 4, pm) TAP(mid, 5, pr)
+                    TAP(top, 0, pl) TAP(top, 1, pm) TAP(top, 2, pr)
 #undef TAP
-                oa[j] = mid; ob[j] = top;
-                if (emit) {
-                    if (!(abl & 4))
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&dn), r_z, zrow + zlane[j], 0, 0);
-                    const float m = fm[j];
-                    const float vx = dn.x * m, vy = dn.y * m, vz = dn.z * m, vw = dn.w * m;
-                    ts[0] += vx; ts[1] += vy; ts[2] += vz; ts[3] += vw;
-                    ts[4] = fmaf(vx, vx, ts[4]); ts[5] = fmaf(vy, vy, ts[5]);
-                    ts[6] = fmaf(vz, vz, ts[6]); ts[7] = fmaf(vw, vw, ts[7]);
+                    dn[j] = o; oa[j] = mid; ob[j] = top;
                 }
             }
+            if (r - 1 >= y0) emit_row(r - 1, dn);
             F64S_STAMP(3)
         }
-        if (y1 == H) {      // the image's last row has no row below it: complete as it stands
-            const unsigned zrow = (unsigned)((H - 1) * W * C) * 4u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 dn = oa[j];
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&dn), r_z, zrow + zlane[j], 0, 0);
-                const float m = fm[j];
-                const float vx = dn.x * m, vy = dn.y * m, vz = dn.z * m, vw = dn.w * m;
-                ts[0] += vx; ts[1] += vy; ts[2] += vz; ts[3] += vw;
-                ts[4] = fmaf(vx, vx, ts[4]); ts[5] = fmaf(vy, vy, ts[5]);
-                ts[6] = fmaf(vz, vz, ts[6]); ts[7] = fmaf(vw, vw, ts[7]);
-            }
-        }
+        if (y1 == H) emit_row(H - 1, oa);      // the image's last row has no row below it: complete as it stands
         // ---- BN partial sums of the band: across the four column groups, then fp64 in LDS
         if (d.out_has_bn) {
 #pragma unroll
@@ -333,9 +392,10 @@ static int fwd64s_rows(int N, int H, int W, int waves) {
     return R;
 }
 
-int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream) {
+template <bool POOL>
+static int launch_fwd64s(const YunetDP* d, hipStream_t stream) {
     static int blocks_per_cu = 0;
-    const void* fn = reinterpret_cast<const void*>(dp_fwd64s_kernel);
+    const void* fn = reinterpret_cast<const void*>(dp_fwd64s_kernel<POOL>);
     if (!blocks_per_cu) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f64s::SMEM) != hipSuccess) return YUNET_EINVAL;
         int nb = 0;
@@ -344,10 +404,15 @@ int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream) {
     }
     if ((long long)d->H * d->W * 64 * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
     int grid = 256 * blocks_per_cu;
-    const int R = fwd64s_rows(d->N, d->H, d->W, grid * f64s::WAVES);
+    int R = fwd64s_rows(d->N, d->H, d->W, grid * f64s::WAVES);
+    if (POOL && (R & 1)) ++R;                                                      // bands hold whole row pairs
     const long long tasks = (long long)d->N * ((d->W + f64s::TW - 1) / f64s::TW) * ((d->H + R - 1) / R);
     const long long need = (tasks + f64s::WAVES - 1) / f64s::WAVES;
     if (need < grid) grid = (int)need;
-    hipLaunchKernelGGL(dp_fwd64s_kernel, dim3(grid), dim3(f64s::NTHR), f64s::SMEM, stream, *d, R);
+    hipLaunchKernelGGL(dp_fwd64s_kernel<POOL>, dim3(grid), dim3(f64s::NTHR), f64s::SMEM, stream, *d, R);
     return hip_status();
+}
+
+int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream) {
+    return d->pool_out ? launch_fwd64s<true>(d, stream) : launch_fwd64s<false>(d, stream);
 }
