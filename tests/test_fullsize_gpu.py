@@ -137,26 +137,129 @@ def _avail_gb():
 TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yunet_n_synth_trained.pth')
 
 
-@pytest.mark.parametrize('kind,h,n,seed,weights', [c + ('init',) for c in CONFIGS] + [('n', 320, 256, 14, 'trained')])
+FULLSTEP = [c + ('init',) for c in CONFIGS] + [('n', 320, 256, 14, 'trained')]
+
+
+def _load_fullstep(kind, h, n, weights):
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(TRAINED), f'fullstep_{kind}_{h}_{n}_{weights}.npz'), allow_pickle=False)
+    return g
+
+
+@pytest.mark.parametrize('kind,h,n,seed,weights', FULLSTEP)
 def test_full_step_vs_oracle(kind, h, n, seed, weights):
-    """The HEADLINE configurations against the CPU oracle at the full batch: one oracle training
-    step on the host (seconds) vs one step of the HIP path.  weights = 'trained' is bench.py's own
-    configuration: the trained-checkpoint-like fixture on structured synthetic faces (SimOTA with
-    dynamic_k 7-9 and real conflicts; random initialisation has k = 1 for 90 % of the GTs).
+    """The HEADLINE configurations against the CPU oracle at the full batch: one oracle training step vs one step
+    of the HIP path.  weights = 'trained' is bench.py's own configuration: the trained-checkpoint-like fixture on
+    structured synthetic faces (SimOTA with dynamic_k 7-9 and real conflicts; random initialisation has k = 1 for
+    90 % of the GTs).
+
+    The oracle's conv stack (one fp32 step and the fp64 gradient yardstick: minutes of host time per case on the
+    GPU box while its GPU idles) was evaluated ONCE on the build box by oracle/make_golden_fullstep.py into
+    tests/golden/fullstep_*.npz; the inputs are regenerated here from the same seeds.  What still runs live is the
+    oracle's SimOTA + losses on the flat the GPU produced (seconds).  YUNET_TEST_LIVE_ORACLE=1 -- or a batch whose
+    end-to-end assignment differs from the fixture's in some image -- runs the whole oracle step live as before
+    (test_full_step_vs_live_oracle below).
 
     Bars:
-      * conv stack: flat [N,P,16] within 5e-4 of the oracle's (max-norm, 20 fp32 layers);
-      * loss step on IDENTICAL inputs (the oracle's SimOTA + losses evaluated on the flat the GPU
-        produced): gt_inds bit-exact except images within fp32 transcendental rounding of a tie
-        (helpers.image_near_tie), the four losses within 1e-4, d loss/d flat within 2e-5 of scale;
-      * end to end (oracle on its own flat): the 5e-4 forward noise may flip the k-th/(k+1)-th
-        candidate of a few GTs out of ~3000 (costs behind the +1e5 penalty are quantised to 2^-7);
-        at most 2 % of the images may differ and the losses then agree to 1e-3 (1e-4 if none do);
-      * every parameter gradient: error against an fp64 evaluation of the same conv stack (fed the
-        GPU's own d loss/d flat) at most 3x the oracle's own fp32 error against fp64 + 0.1 %
-        (round 2: 0.2 %, worst measured ratio 0.53);
+      * conv stack: flat [N,P,16] within 5e-4 of the oracle's (max-norm, 20 fp32 layers; a strided sample);
+      * loss step on IDENTICAL inputs (the oracle's SimOTA + losses evaluated on the flat the GPU produced): gt_inds
+        bit-exact except images within fp32 transcendental rounding of a tie (helpers.image_near_tie), the four
+        losses within 1e-4, d loss/d flat within 2e-5 of scale;
+      * end to end (oracle on its own flat): the 5e-4 forward noise may flip the k-th/(k+1)-th candidate of a few GTs
+        out of ~3000 (costs behind the +1e5 penalty are quantised to 2^-7); at most 2 % of the images may differ and
+        the losses then agree to 1e-3 (1e-4 if none do);
+      * every parameter gradient, ALL shapes: error against the fp64 evaluation of the same conv stack at most 3x the
+        oracle's own fp32 error against fp64 + 0.1 %;
       * BatchNorm running statistics after the step.
     """
+    if os.environ.get('YUNET_TEST_LIVE_ORACLE'):
+        return _full_step_vs_live_oracle(kind, h, n, seed, weights)
+    import numpy as np
+    import yunet_amd
+    import yunet_amd.synthetic as S
+    import make_golden_fullstep as MG
+    fx = _load_fullstep(kind, h, n, weights)
+    assert int(fx['seed']) == seed
+    cfg = yunet_amd.Config.fromfile(f'configs/yunet_{kind}.py')
+    model = yunet_amd.build_detector(cfg.model)
+    arch, sd, b = MG.case_inputs(kind, h, n, seed, weights)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).train()
+    sizes = C.featmap_sizes(h, h)
+
+    # ---- HIP path
+    losses_g = model.forward_train(**S.to_device(b, DEV))
+    sum(losses_g.values()).backward()
+    torch.cuda.synchronize()
+    plan = model.engine.plan
+    flat_g, dflat_g, gi_g = plan.flat.cpu(), plan.dflat.cpu(), plan.gt_inds.cpu()
+    lg = {k: float(v) for k, v in losses_g.items()}
+    grads_g = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    sd_g = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    stride = int(fx['stride'])
+
+    # (1) conv stack forward
+    assert float((flat_g[:, ::stride, :] - torch.from_numpy(fx['flat_sample'])).abs().max()) <= 5e-4 * float(fx['flat_scale'])
+
+    # (2) loss step on identical inputs (live: the oracle's SimOTA + losses on the GPU's flat)
+    fl2 = flat_g.clone().requires_grad_(True)
+    l2_t, aux2 = O.loss_step(fl2, b['gt_bboxes'], b['gt_labels'], b['gt_keypointss'], sizes, arch)
+    sum(l2_t.values()).backward()
+    gi2 = aux2['gt_inds'].int()
+    bad = [i for i in range(n) if not torch.equal(gi_g[i], gi2[i])]
+    unexplained = [i for i in bad if not Hh.image_near_tie(flat_g[i], b['gt_bboxes'][i], sizes)]
+    assert not unexplained, f'assignment differs from the oracle on identical inputs: images {unexplained}'
+    assert len(bad) <= 1, bad
+    if not bad:
+        for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
+            assert abs(lg[k] - float(l2_t[k])) <= 1e-4 * abs(float(l2_t[k])) + 1e-6, (k, lg[k], float(l2_t[k]))
+        assert float((dflat_g - fl2.grad).abs().max()) <= 2e-5 * float(fl2.grad.abs().max()) + 1e-8
+
+    # (3) end to end against the fixture's assignment and losses
+    gi_o = torch.zeros(n, int(fx['num_priors']), dtype=torch.int32)
+    pos = torch.from_numpy(fx['pos']).long()
+    gi_o[pos[:, 0], pos[:, 1]] = pos[:, 2].int()
+    diff = [i for i in range(n) if not torch.equal(gi_g[i], gi_o[i])]
+    assert len(diff) <= max(1, n // 50), f'{len(diff)} of {n} images assigned differently end to end'
+    if diff:
+        # the fixture's gradients belong to ITS assignment: judge this batch against a live oracle step
+        return _full_step_vs_live_oracle(kind, h, n, seed, weights)
+    lo = dict(zip(('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'), fx['losses'][:4]))
+    for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
+        assert abs(lg[k] - lo[k]) <= 1e-4 * abs(lo[k]) + 1e-6, (k, lg[k], lo[k])
+    assert int((gi_g > 0).sum()) > n        # a real assignment, not an empty one
+    if weights == 'trained':
+        npos_per_gt = float((gi_g > 0).sum()) / sum(int(t.shape[0]) for t in b['gt_bboxes'])
+        assert npos_per_gt > 3.0, f'trained fixture: {npos_per_gt:.2f} positives per GT -- dynamic_k > 1 is not exercised'
+
+    # (4) parameter gradients against the fp64 yardstick of the fixture (identical assignment: the GPU's and the
+    #     oracle's d loss / d flat agree to 2e-5, far inside the bar)
+    keys = [str(k) for k in fx['keys']]
+    assert keys == O.param_keys(sd)
+    off, g64 = fx['offsets'], torch.from_numpy(fx['grad64']).double()
+    scale = float(max(fx['amax64']))
+    worst = (0.0, None)
+    for i, k in enumerate(keys):
+        a = g64[off[i]:off[i + 1]].reshape(grads_g[k].shape)
+        err_hip = float((grads_g[k] - a).abs().max())
+        tol = 3 * max(float(fx['err_ref'][i]), 1e-5 * scale) + 1e-3 * float(fx['amax64'][i])
+        worst = max(worst, (err_hip / tol, k))
+        assert err_hip <= tol, (k, err_hip, float(fx['err_ref'][i]), float(fx['amax64'][i]), scale)
+    print(f'[full step {kind}-{h}-{n}-{weights}] worst gradient error / tolerance: {worst[0]:.3f} at {worst[1]} (fixture)')
+
+    # (5) BN running statistics
+    boff, bvals = fx['bn_offsets'], torch.from_numpy(fx['bn_vals'])
+    for i, k in enumerate(str(x) for x in fx['bn_keys']):
+        v = bvals[boff[i]:boff[i + 1]].reshape(sd_g[k].shape)
+        if k.endswith('num_batches_tracked'):
+            assert int(sd_g[k]) == int(v)
+        else:
+            assert torch.allclose(sd_g[k], v, rtol=1e-3, atol=1e-4), k
+
+
+def _full_step_vs_live_oracle(kind, h, n, seed, weights):
+    """The same comparison with the whole oracle step (fp32 conv stack + fp64 gradient yardstick) evaluated live on the
+    host: what test_full_step_vs_oracle did before round 4; minutes of host time per case."""
     import yunet_amd
     import yunet_amd.synthetic as S
     cfg = yunet_amd.Config.fromfile(f'configs/yunet_{kind}.py')
@@ -232,7 +335,7 @@ def test_full_step_vs_oracle(kind, h, n, seed, weights):
     #  shape -- both weight sets -- and the other two BASELINE shapes are held to the oracle's fp32 gradients at the
     #  bar two fp32 evaluations of this stack agree to; YUNET_TEST_FP64_ALL=1 runs the yardstick everywhere)
     need_gb = 0.1 * n * (h / 320.0) ** 2 * 1.3
-    want_fp64 = (kind, h, n) == ('n', 320, 256) or bool(os.environ.get('YUNET_TEST_FP64_ALL'))
+    want_fp64 = True
     if want_fp64 and _avail_gb() > need_gb:
         sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         leaf64 = {k: sd64[k].clone().requires_grad_(True) for k in keys}
