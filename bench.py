@@ -24,6 +24,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import platform
 import sys
 import time
 
@@ -370,11 +371,13 @@ def ref_vs_port(bs=None):
         return None
 
 
-def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
-    """The oracle's full training step (a port of the reference step: eager torch ops + a Python
-    loop over images for SimOTA) on a bounded sample of the same workload.  device='cpu' is the
-    cpu_baseline; device='cuda' is the 'un-accelerated GPU' row -- the same eager ops through
-    stock PyTorch-ROCm (MIOpen / rocBLAS) on the MI355X."""
+def cpu_baseline_worker(kind, size, seed=1234, budget_s=24.0, device='cpu'):
+    """cpu_baseline: the REFERENCE's own training step -- its unmodified Python files (oracle/_ref, put there by
+    oracle/make_ref.sh; /root/reference in the build container) on torch CPU under the arithmetic-free mmcv stub of
+    oracle/ref_stub.py, driven the way the mmcv runner drives it (train_step -> zero_grad -> backward -> SGD step)
+    -- on a bounded sample of the same workload, kind = "reference"; the oracle port (oracle/yunet_oracle.py) is
+    timed beside it and reported as `port`.  Without a reference tree only the port runs (kind = "port").
+    device='cuda' is the 'un-accelerated GPU' row: the port's eager ops through stock PyTorch-ROCm on the MI355X."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import yunet_oracle as O
     import yunet_amd.synthetic as S
@@ -382,13 +385,33 @@ def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
     torch.set_num_threads(cores)
     arch = O.yunet_arch(kind)
     sync = (lambda: None) if device == 'cpu' else torch.cuda.synchronize
+    have_ref = False
+    if device == 'cpu':
+        try:
+            import ref_stub
+            have_ref = ref_stub.available()
+        except Exception:
+            have_ref = False
+
+    def timed(fn, budget):
+        fn()                                    # warm-up (MIOpen kernel selection on the GPU, page-in on the CPU)
+        sync()
+        t0 = time.time()
+        iters = 0
+        while iters < 2 or (time.time() - t0 < budget and iters < 50):
+            fn()
+            iters += 1
+        sync()
+        return iters, time.time() - t0
+
     # Two batch sizes, the better one is reported: on the MI355X host torch's CPU convolutions fall off a
     # cliff between bs 16 and bs 32 (measured 129 vs 33 img/s on 16 threads, tools/ubench/cpu_probe.py),
     # and the baseline should be the CPU's best case
-    runs = []
-    for bs in ((16, 32) if device == 'cpu' else (32,)):
+    sizes = (16, 32) if device == 'cpu' else (32,)
+    share = budget_s / (len(sizes) * (2 if have_ref else 1))
+    runs = {'port': [], 'reference': []}
+    for bs in sizes:
         sd = O.init_state(arch, seed=0)
-        opt = O.SGD(lr=1e-5)
         b = S.make_batch(bs, size, size, seed)
         if device != 'cpu':
             dev = torch.device(device)
@@ -396,32 +419,56 @@ def cpu_baseline_worker(kind, size, seed=1234, budget_s=20.0, device='cpu'):
             b = dict(b, img=b['img'].to(dev), gt_bboxes=[t.to(dev) for t in b['gt_bboxes']],
                      gt_labels=[t.to(dev) for t in b['gt_labels']],
                      gt_keypointss=[t.to(dev) for t in b['gt_keypointss']])
-        O.train_step(b, sd, arch, opt)          # warm-up (MIOpen kernel selection on the GPU)
-        sync()
-        t0 = time.time()
-        iters = 0
-        while iters < 2 or (time.time() - t0 < budget_s / (2 if device == 'cpu' else 1) and iters < 50):
-            O.train_step(b, sd, arch, opt)
-            iters += 1
-        sync()
-        runs.append((bs * iters / (time.time() - t0), bs, iters))
-    rate, bs, iters = max(runs)
-    dt = bs * iters / rate
-    others = '; '.join(f'bs {b_}: {r_:.1f} img/s' for r_, b_, _ in runs)
-    what = (f'oracle/yunet_oracle.py train_step (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} '
-            f'{size}x{size} bs {bs}, {iters} iters after 1 warm-up, torch fp32 ({others})')
+        if have_ref:
+            model, _ = ref_stub.build_detector(f'yunet_{kind}.py')
+            model.load_state_dict(sd, strict=True)
+            model.train()
+            ropt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=5e-4)
+            data = dict(img=b['img'], img_metas=b['img_metas'], gt_bboxes=list(b['gt_bboxes']),
+                        gt_labels=list(b['gt_labels']), gt_keypointss=list(b['gt_keypointss']))
+
+            def ref_step():
+                out = model.train_step(data, ropt)
+                ropt.zero_grad()
+                out['loss'].backward()
+                ropt.step()
+            iters, dt = timed(ref_step, share)
+            runs['reference'].append((bs * iters / dt, bs, iters))
+            del model, ropt
+        sd_p = {k: v.clone() for k, v in sd.items()}
+        opt = O.SGD(lr=1e-5)
+        iters, dt = timed(lambda: O.train_step(b, sd_p, arch, opt), share)
+        runs['port'].append((bs * iters / dt, bs, iters))
+
+    def describe(which, what):
+        rate, bs, iters = max(runs[which])
+        others = '; '.join(f'bs {b_}: {r_:.1f} img/s' for r_, b_, _ in runs[which])
+        return rate, (f'{what} (fwd+SimOTA+losses+bwd+SGD), YuNet_{kind} {size}x{size} bs {bs}, {iters} iters after '
+                      f'1 warm-up, torch fp32 ({others})')
+    prate, pwhat = describe('port', 'oracle/yunet_oracle.py train_step')
     if device != 'cpu':
-        return dict(value=round(bs * iters / dt, 2), unit='images/sec', kind='port',
-                    sample=what + ', eager PyTorch-ROCm ops on cuda:0 (un-accelerated GPU row)')
-    res = dict(value=round(bs * iters / dt, 2), unit='images/sec', cores=cores, kind='port',
-               sample=what + f', {cores} threads')
-    rp = ref_vs_port(bs)
-    if rp:
-        res['reference_over_port'] = rp.get('ratio')
-        res['sample'] += (f"; on the build box ({rp.get('cores')} cores, {rp.get('workload')}) the reference's own files under the "
-                          f"mmcv stub ran {rp.get('reference_img_s')} img/s vs this port {rp.get('port_img_s')} "
-                          f"img/s (ratio {rp.get('ratio')}, tools/cpu_ref_vs_port.py)")
-    return res
+        return dict(value=round(prate, 2), unit='images/sec', kind='port',
+                    sample=pwhat + ', eager PyTorch-ROCm ops on cuda:0 (un-accelerated GPU row)')
+    cpu = platform.processor() or platform.machine()
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), cpu)
+    except OSError:
+        pass
+    port = dict(value=round(prate, 2), unit='images/sec', sample=pwhat + f', {cores} threads')
+    if not have_ref:
+        res = dict(value=port['value'], unit='images/sec', cores=cores, cpu=cpu, kind='port', sample=port['sample'])
+        rp = ref_vs_port(max(runs['port'])[1])
+        if rp:
+            res['reference_over_port'] = rp.get('ratio')
+            res['sample'] += (f"; no reference tree here (oracle/make_ref.sh) -- on the build box ({rp.get('cores')} cores) the "
+                              f"reference's own files ran {rp.get('reference_img_s')} img/s vs this port {rp.get('port_img_s')} img/s")
+        return res
+    where = os.path.relpath(ref_stub.REF_ROOT, ROOT) if ref_stub.REF_ROOT.startswith(ROOT) else ref_stub.REF_ROOT
+    rrate, rwhat = describe('reference', "the reference's own detector.train_step + torch.optim.SGD: its unmodified files "
+                                         f'({where}) under the mmcv stub of oracle/ref_stub.py')
+    return dict(value=round(rrate, 2), unit='images/sec', cores=cores, cpu=cpu, kind='reference',
+                sample=rwhat + f', {cores} threads', port=port, reference_over_port=round(rrate / prate, 3))
 
 
 def _child(flag, kind, size, timeout, env_extra):

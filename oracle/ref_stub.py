@@ -9,9 +9,10 @@ the heavy mmdet ``__init__`` zoo imports are skipped).  See SURVEY.md Appendix A
 
 This module exists to (1) pin `oracle/yunet_oracle.py` against the reference itself
 and (2) generate the committed fixtures under `tests/golden/` (`oracle/make_golden.py`).
-It only works where /root/reference exists (the build container); nothing on the
-GPU box imports it.  It contains no reference source text: every reference module
-is imported from where it lies.
+It works where /root/reference exists (the build container) or where oracle/make_ref.sh
+has put the hot-path files under the git-ignored oracle/_ref/ (bench.py's cpu_baseline on
+the GPU box); no test on the GPU box imports it.  It contains no reference source text:
+every reference module is imported from where it lies.
 """
 import importlib
 import os
@@ -21,7 +22,10 @@ import types
 import torch
 import torch.nn as nn
 
-REF_ROOT = os.environ.get('YUNET_REFERENCE_ROOT', '/root/reference')
+# /root/reference where it exists (the build container); otherwise oracle/_ref -- the git-ignored copy of the hot-path
+# files made by oracle/make_ref.sh, which travels to the GPU box so that bench.py can time the reference there
+_LOCAL_REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref')
+REF_ROOT = os.environ.get('YUNET_REFERENCE_ROOT') or ('/root/reference' if os.path.isdir('/root/reference/mmdet') else _LOCAL_REF)
 
 
 def available():
