@@ -54,6 +54,8 @@ def parse():
     p.add_argument('--no-gpu-eager', action='store_true',
                    help='skip the un-accelerated-GPU row (the oracle\'s eager torch ops on cuda:0)')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-other-configs', action='store_true',
+                   help='skip the 10-step windows of BASELINE.json configs[2..4] after the headline')
     p.add_argument('--no-exact-bwd', action='store_true',
                    help='skip the second timing with the exact-fp32 backward matrix instruction (exact_fp32_bwd)')
     p.add_argument('--no-live-traffic', action='store_true',
@@ -216,7 +218,7 @@ def live_traffic(kernel, a):
         try:
             subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '-o', 'p',
                             '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1',
-                            '--no-cpu-baseline', '--no-roofline', '--no-exact-bwd', '--kind', a.kind, '--size', str(a.size),
+                            '--no-cpu-baseline', '--no-roofline', '--no-exact-bwd', '--no-other-configs', '--kind', a.kind, '--size', str(a.size),
                             '--batch', str(a.batch), '--weights', a.weights, '--dtype', a.dtype],
                            capture_output=True, timeout=90, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))
             csvs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith('counter_collection.csv')]
@@ -331,6 +333,81 @@ def profile_ops(eng, reps=3):
             sh['ms'] /= reps
             sh['bytes'] //= reps
     return agg
+
+
+def gpu_clock_mhz(index=0):
+    """Current shader clock of the GPU in MHz (the starred level of pp_dpm_sclk), None where sysfs does not say."""
+    import glob
+    cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
+    if not cards:
+        return None
+    try:
+        for line in open(cards[min(index, len(cards) - 1)]):
+            if line.rstrip().endswith('*'):
+                return int(''.join(ch for ch in line.split(':', 1)[1] if ch.isdigit()))
+    except Exception:
+        pass
+    return None
+
+
+def plan_reference_graph_bytes(eng):
+    """Bytes one step moves over the REFERENCE's op graph (op_bytes_reference_graph summed over the plan)."""
+    import yunet_amd._lib as L
+    plan = eng.plan
+    return sum(op_bytes_reference_graph(arr[k], L) for arr in (plan.c_fwd_a, plan.c_fwd_b, plan.c_bwd)
+               for k in range(len(arr)))
+
+
+def run_other_config(kind, size, batch, dtype, dev, steps=10, warmup=3):
+    """One of BASELINE.json's other single-GPU configurations, timed in this process after the headline: the same
+    full step (fwd + SimOTA + losses + bwd + SGD) on a fresh model, `steps` steps after `warmup`, inputs resident."""
+    import yunet_amd
+    import yunet_amd.synthetic as S
+    from yunet_amd.optim import FusedSGD
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', f'yunet_{kind}.py'))
+    torch.manual_seed(0)
+    model = yunet_amd.build_detector(cfg.model).to(dev)
+    model.train()
+    if dtype == 'bf16':
+        model.set_precision('bf16')
+    opt = FusedSGD(model, lr=cfg.optimizer['lr'] * 0.001, momentum=cfg.optimizer['momentum'],
+                   weight_decay=cfg.optimizer['weight_decay'])
+    fixture = os.path.join(ROOT, 'tests', 'golden', 'yunet_n_synth_trained.pth')
+    trained = kind == 'n' and size == H and os.path.exists(fixture)
+    if trained:
+        model.load_state_dict(torch.load(fixture, map_location='cpu', weights_only=False)['state_dict'], strict=True)
+    pool = []
+    for i in range(2):
+        b = S.make_batch(batch, size, size, S.batch_seed(0, i), with_img=not trained)
+        if trained:
+            gen = torch.Generator(device=dev).manual_seed(S.batch_seed(0, i))
+            img = torch.rand(batch, 3, size, size, generator=gen, device=dev) * 255.0
+            b['img'] = S.render_faces(img, b['gt_bboxes'], b['gt_keypointss'])
+        pool.append(S.to_device(b, dev))
+
+    def step(i):
+        out = model.train_step(pool[i % 2], opt)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+        return out
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1000.0 * dt / steps
+    res = {'ms_per_step': round(ms, 3), 'value': round(batch * steps / dt, 1), 'unit': 'images/sec', 'steps': steps,
+           'warmup': warmup, 'dtype': dtype,
+           'step_reference_graph_GBs': round(plan_reference_graph_bytes(model.engine) / (ms * 1e-3) / 1e9, 1),
+           'final_loss': round(float(out['log_vars']['loss']), 4),
+           'weights': 'trained fixture + structured faces' if trained else 'random init + noise images'}
+    del model, opt, pool
+    torch.cuda.empty_cache()
+    return res
 
 
 def effective_cores():
@@ -570,6 +647,7 @@ def main():
     if world > 1:
         dist.barrier(**bar)
     torch.cuda.synchronize()
+    clk0 = gpu_clock_mhz(local)
     t0 = time.perf_counter()
     for i in range(a.steps):
         out = step(i)
@@ -578,6 +656,7 @@ def main():
         dist.barrier(**bar)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    clk1 = gpu_clock_mhz(local)
     comm = model.engine.comm_report(a.steps) if world > 1 else None
     per_rank = [dt]
     if world > 1:
@@ -608,6 +687,9 @@ def main():
                                    'cores through bf16 splits (forward 3-way: 2.4e-7 of the exact fp32 instruction)',
                        'parallelism': f'dp{world}', 'global_batch': world * a.batch},
             'final_loss': round(last_loss, 4),
+            # shader clock (sysfs pp_dpm_sclk) right before / right after the timed window: a 0.1 s window can sit on
+            # the clock ramp
+            'gpu_clock_mhz': {'before': clk0, 'after': clk1},
             'weights': ('tests/golden/yunet_n_synth_trained.pth + structured synthetic faces' if trained
                         else 'random init + noise images'),
             'per_rank_images_per_sec': [round(a.batch * a.steps / t, 1) for t in per_rank],
@@ -681,10 +763,26 @@ def main():
         res['exact_fp32_bwd'] = {'ms_per_step': round(1000.0 * dte / a.steps, 3),
                                  'value': round(a.batch * a.steps / dte, 1), 'unit': 'images/sec',
                                  'what': 'same run, option bwd_fp32mma=1: every backward GEMM on v_mfma_f32_16x16x4_f32'}
+    headline = (a.kind, a.size, a.batch, a.dtype, a.weights) == (KIND, H, BATCH, 'f32', 'trained')
+    if rank == 0 and world == 1 and headline and not a.no_other_configs:
+        # BASELINE.json configs[2] / [3] / [4] on one GPU, 10-step windows in this same process
+        del wrapped, opt, pool
+        model.engine.release() if hasattr(model.engine, 'release') else None
+        del model
+        torch.cuda.empty_cache()
+        res['other_configs'] = {}
+        for name, (k_, s_, b_, d_) in (('YuNet_n 320x320 bs=256, bf16 fwd / fp32 grads', ('n', 320, 256, 'bf16')),
+                                       ('YuNet_n 640x640 bs=64, fp32', ('n', 640, 64, 'f32')),
+                                       ('YuNet_s 320x320 bs=512, fp32', ('s', 320, 512, 'f32'))):
+            try:
+                res['other_configs'][name] = run_other_config(k_, s_, b_, d_, dev)
+            except Exception as e:                           # a side measurement must not cost the headline line
+                res['other_configs'][name] = {'error': repr(e)[:200]}
+        model = wrapped = opt = pool = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(a.kind, a.size)
         if not a.no_gpu_eager:
-            del model, wrapped, opt, pool          # hand the GPU to the child process
+            model = wrapped = opt = pool = None    # hand the GPU to the child process
             torch.cuda.empty_cache()
             res['cpu_baseline']['gpu_eager'] = gpu_eager(a.kind, a.size)
     if rank == 0:
