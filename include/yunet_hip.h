@@ -223,6 +223,10 @@ typedef struct YunetLossCfg {
     float box_eps;               /* EIoULoss/DIoULoss eps (1e-6)                       */
     float smooth_point;          /* EIoU 0.1                                           */
     float kps_beta;              /* SmoothL1 beta (1/9)                                */
+    int32_t defer_num_total;     /* ABI 6, multi-GPU: 1 = norm[0] is NOT read -- loss_cls / loss_bbox / loss_obj and
+                                  * their d/d(flat) leave yunet_loss un-normalised; yunet_loss_finalize_ex applies
+                                  * 1 / max(num_total, 1) once the all-reduce of num_pos (yunet_head.py:493-497) has
+                                  * landed, so that collective runs beside the loss kernel instead of in front of it */
 } YunetLossCfg;
 
 /* The four YuNet_Head losses and d(loss_i)/d(flat) in one pass (yunet_head.py:506-532,
@@ -240,6 +244,14 @@ int yunet_loss(const float* flat, const int32_t* gt_inds, const float* max_overl
                float* dflat, float* partials, int blocks, void* stream);
 int yunet_loss_finalize(const float* partials, int blocks, float* losses, float* mirror,
                         void* stream);
+/* The same with the deferred normaliser of YunetLossCfg.defer_num_total: num_total (device, nullable) = the
+ * all-reduced mean num_pos; the first three losses are multiplied by 1 / max(num_total[0], 1) and dy_norm [16]
+ * (nullable) receives the per-channel factor of d(loss)/d(flat) -- that value for cls | dx dy dw dh | obj, 1 for the
+ * ten kps channels (normalised by the rank-local weight sum inside yunet_loss) -- which the fused head units take
+ * as YunetDP.dy_scale.  (x * 1.0 is exact: gradients are bit-identical to the undeferred form.)
+ * In an op list: YUNET_OP_LOSS_FINALIZE with p[3] = num_total, p[4] = dy_norm. */
+int yunet_loss_finalize_ex(const float* partials, int blocks, float* losses, float* mirror,
+                           const float* num_total, float* dy_norm, void* stream);
 int yunet_loss_blocks(int N, int P);
 
 /* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */

@@ -49,7 +49,7 @@ class YunetLevels(C.Structure):
 class YunetLossCfg(C.Structure):
     _fields_ = [('box_loss', C.c_int32), ('w_cls', C.c_float), ('w_box', C.c_float),
                 ('w_obj', C.c_float), ('w_kps', C.c_float), ('box_eps', C.c_float),
-                ('smooth_point', C.c_float), ('kps_beta', C.c_float)]
+                ('smooth_point', C.c_float), ('kps_beta', C.c_float), ('defer_num_total', C.c_int32)]
 
 
 class YunetAugCfg(C.Structure):
@@ -109,6 +109,7 @@ _SIGNATURES = {
                                                 C.c_void_p] + [C.c_int] * 3 +
                    [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'yunet_loss_finalize_ex': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),

@@ -250,7 +250,8 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
                                 (float*)o.p[7], o.i[3], stream);
                 break;
             case YUNET_OP_LOSS_FINALIZE:
-                rc = yunet_loss_finalize((const float*)o.p[0], o.i[0], (float*)o.p[1], (float*)o.p[2], stream);
+                rc = yunet_loss_finalize_ex((const float*)o.p[0], o.i[0], (float*)o.p[1], (float*)o.p[2],
+                                            (const float*)o.p[3], (float*)o.p[4], stream);
                 break;
             case YUNET_OP_SGD: {
                 const int64_t n = ((int64_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];

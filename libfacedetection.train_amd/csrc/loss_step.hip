@@ -498,7 +498,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
     const float* __restrict__ max_overlaps, const float* __restrict__ gt_boxes,
     const float* __restrict__ gt_kps, Levels L, YunetLossCfg cfg, const float* __restrict__ norm,
     int N, int P, int Gmax, float* __restrict__ dflat, float* __restrict__ partials) {
-    const float num_total = fmaxf(norm[0], 1.0f);
+    // cfg.defer_num_total: norm[0] (the all-reduced positives, possibly still in flight on another stream) is NOT
+    // read: the cls / bbox / obj terms and their gradients leave this kernel un-normalised (x 1.0 is exact) and
+    // loss_finalize_kernel applies 1 / max(num_total, 1) to the losses and hands it to the head backward as dy_scale
+    const float num_total = cfg.defer_num_total ? 1.0f : fmaxf(norm[0], 1.0f);
     const float inv_total = 1.0f / num_total;
     const float kps_den = norm[1] + 1.1920928955078125e-07f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -538,8 +541,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
                         ? eiou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.smooth_point, cfg.box_eps)
                         : diou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps);
             acc[1] += lb.v;
-            const float kb = cfg.w_box * inv_total;
-            o[1] = lb.d[0] * kb; o[2] = lb.d[1] * kb; o[3] = lb.d[2] * kb; o[4] = lb.d[3] * kb;
+            // (d * w) * 1/num_total, in this order: with the deferred normaliser the last factor is applied by the head
+            // backward (dy_scale) and the product must round the same way
+            const float kb = cfg.w_box;
+            o[1] = lb.d[0] * kb * inv_total; o[2] = lb.d[1] * kb * inv_total;
+            o[3] = lb.d[2] * kb * inv_total; o[4] = lb.d[3] * kb * inv_total;
             // kps: smooth-L1 on (kps - prior_xy)/stride, weight = mean visibility
             const float* kp = gt_kps + ((size_t)n * Gmax + g) * 15;
             const float w = ((((kp[2] + kp[5]) + kp[8]) + kp[11]) + kp[14]) / 5.0f;
@@ -586,7 +592,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
 }
 
 __global__ void loss_finalize_kernel(const float* __restrict__ partials, int blocks,
-                                     float* __restrict__ losses, float* __restrict__ mirror) {
+                                     float* __restrict__ losses, float* __restrict__ mirror,
+                                     const float* __restrict__ num_total, float* __restrict__ dy_norm) {
     // 4 waves, one per loss term; fp64 accumulation in a fixed order
     __shared__ float s_l[4];
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -594,7 +601,10 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partials, int blo
     for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 4 + k];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) s_l[k] = (float)v;
+    // deferred normaliser (yunet_loss with cfg.defer_num_total): cls, bbox and obj arrive un-normalised
+    const float inv = num_total ? 1.0f / fmaxf(num_total[0], 1.0f) : 1.0f;
+    if (lane == 0) s_l[k] = (num_total && k < 3) ? (float)v * inv : (float)v;
+    if (dy_norm && threadIdx.x < 16) dy_norm[threadIdx.x] = threadIdx.x < 6 ? inv : 1.0f;   // cls | box x4 | obj | kps x10
     __syncthreads();
     // losses[4] = the total the reference builds in _parse_losses (base.py:206-209): a python sum()
     // over the dict in insertion order, i.e. ((cls + bbox) + obj) + kps in fp32
@@ -669,9 +679,14 @@ extern "C" int yunet_loss(const float* flat, const int32_t* gt_inds, const float
     return -(int)hipGetLastError();
 }
 
+extern "C" int yunet_loss_finalize_ex(const float* partials, int blocks, float* losses, float* mirror,
+                                      const float* num_total, float* dy_norm, void* stream) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials,
+                       blocks, losses, mirror, num_total, dy_norm);
+    return -(int)hipGetLastError();
+}
+
 extern "C" int yunet_loss_finalize(const float* partials, int blocks, float* losses, float* mirror,
                                    void* stream) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials,
-                       blocks, losses, mirror);
-    return -(int)hipGetLastError();
+    return yunet_loss_finalize_ex(partials, blocks, losses, mirror, nullptr, nullptr, stream);
 }

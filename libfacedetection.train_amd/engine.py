@@ -343,6 +343,9 @@ class Plan:
         self.loss_blocks = lib.yunet_loss_blocks(n, self.P)
         self.loss_partials = torch.empty(self.loss_blocks, 4, **f32)
         self.dy_scale = torch.ones(16, **f32)
+        self.dy_norm = torch.ones(16, **f32)      # deferred normaliser: per-channel 1 / num_total (loss_finalize_ex)
+        self.dy_up = torch.ones(16, **f32)        # deferred mode: the upstream loss scales; dy_scale = dy_up * dy_norm
+        self.deferred = False
         op = self._op(L.OP_ASSIGN,
                       p=[self.flat.data_ptr(), self.gt_boxes.data_ptr(), self.gt_kps.data_ptr(),
                          None, self.gt_count.data_ptr(), self.gt_inds.data_ptr(), None,
@@ -417,6 +420,20 @@ class Plan:
         self.c_fwd_a = self._carray(self.fwd_a)
         self.c_fwd_b = self._carray(self.fwd_b)
         self.c_bwd = self._carray(self.bwd)
+        # N > 1: the same two phases with the num_pos normaliser DEFERRED -- the loss kernel leaves the cls / bbox /
+        # obj terms un-normalised and does not read norm[0], so its all-reduce runs on the side stream BESIDE the
+        # loss kernel; loss_finalize applies 1 / max(num_total, 1) to the logged losses and writes the per-channel
+        # factor the fused head units take as dy_scale (engine.forward / backward).  x 1.0 is exact: the gradients
+        # are bit-identical to the undeferred form.
+        assert self.fwd_b[0].opcode == L.OP_LOSS and self.fwd_b[1].opcode == L.OP_LOSS_FINALIZE
+        loss_def, fin_def = L.YunetOp(), L.YunetOp()
+        C.memmove(C.byref(loss_def), C.byref(self.fwd_b[0]), C.sizeof(L.YunetOp))
+        C.memmove(C.byref(fin_def), C.byref(self.fwd_b[1]), C.sizeof(L.YunetOp))
+        loss_def.loss.defer_num_total = 1
+        fin_def.p[3] = self.norm.data_ptr()
+        fin_def.p[4] = self.dy_norm.data_ptr()
+        self.c_fwd_b_loss = self._carray([loss_def])
+        self.c_fwd_b_rest = self._carray([fin_def] + self.fwd_b[2:])
 
         # ---- world > 1: the same backward in TWO segments so that the gradient all-reduce of the
         # first bucket (head, neck and the backbone stages from the first pyramid tap on: the tail
@@ -798,10 +815,31 @@ class YuNetEngine:
         self.stage_gt(plan, gt_bboxes, gt_keypointss)
         plan.set_img(img)
         self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')
-        self.reduce_num_pos(plan.norm)
-        self._exec(plan.c_fwd_b, 'yunet_exec(fwd_b)')
+        was_deferred = plan.deferred
+        plan.deferred = self.world_size > 1 or (self.always_bucket and torch.distributed.is_initialized())
+        if was_deferred and not plan.deferred:
+            plan.dy_scale.fill_(1.0)     # (tests flip the mode on one plan) no stale 1 / num_total in the head scales
+        if plan.deferred:
+            # reduce_mean(num_pos) (yunet_head.py:493-497) on the side stream beside the loss kernel; the launch
+            # stream waits for it only in front of loss_finalize
+            main, side = torch.cuda.current_stream(), self._comm_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.reduce_num_pos(plan.norm, side)
+            self._exec(plan.c_fwd_b_loss, 'yunet_exec(fwd_b: loss)')
+            main.wait_stream(side)
+            self._exec(plan.c_fwd_b_rest, 'yunet_exec(fwd_b: finalize)')
+        else:
+            self._exec(plan.c_fwd_b, 'yunet_exec(fwd_b)')
         self.params.num_batches_tracked += 1
         return plan.losses
+
+    def scale_buffer(self):
+        """Where the upstream scales of the four losses go (16 head channels: cls | box x4 | obj | kps x10): the
+        vector the fused head units read as dy_scale -- or, with the deferred num_pos normaliser (N > 1), its
+        un-normalised half, which backward() multiplies by loss_finalize's per-channel 1 / num_total."""
+        plan = self.plan
+        return plan.dy_up if plan.deferred else plan.dy_scale
 
     def backward(self, grad_scales=None):
         """d(sum_i s_i * loss_i)/d(params) -> params.grad (overwritten)."""
@@ -809,7 +847,10 @@ class YuNetEngine:
         if grad_scales is not None:
             s = [float(v) for v in grad_scales]
             vec = [s[0]] + [s[1]] * 4 + [s[2]] + [s[3]] * 10
-            plan.dy_scale.copy_(torch.tensor(vec, dtype=torch.float32), non_blocking=True)
+            self.scale_buffer().copy_(torch.tensor(vec, dtype=torch.float32), non_blocking=True)
+        if plan.deferred:
+            # x the deferred 1 / num_total of the cls | box | obj channels (written by loss_finalize)
+            torch.mul(plan.dy_up, plan.dy_norm, out=plan.dy_scale)
         if (self.world_size <= 1 and not self.always_bucket) or plan.split_off is None:
             self._exec(plan.c_bwd, 'yunet_exec(bwd)')
             self.allreduce_grads()
@@ -871,13 +912,14 @@ class YuNetEngine:
             torch.distributed.all_reduce(t, group=pg)
             t.div_(self.world_size)
 
-    def reduce_num_pos(self, norm):
+    def reduce_num_pos(self, norm, stream=None):
         """reduce_mean(num_pos) (mmdet/core/utils/dist_utils.py:68-74, yunet_head.py:493-497):
-        every rank holds num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound."""
+        every rank holds num_pos/world in norm[0]; SUM over ranks.  4 bytes, latency-bound; issued on the side
+        stream, beside the loss kernel (forward())."""
         if self.world_size > 1 or (self.always_bucket and torch.distributed.is_initialized()):
-            e0 = self._comm_mark(None)
+            e0 = self._comm_mark(stream)
             torch.distributed.all_reduce(norm[0:1], group=self.process_group)
-            self._comm_mark(None, ('num_pos', e0))
+            self._comm_mark(stream, ('num_pos', e0))
 
     def allreduce_grads(self):
         """DDP gradient mean in ONE collective over [logged scalars | flat gradient]

@@ -104,11 +104,11 @@ class _EngineStep(torch.autograd.Function):
         eng = model.engine
         if g0 is None and g1 is None and g2 is None and g3 is None and gt is not None:
             # loss = total: one upstream scalar scales all 16 head channels
-            eng.plan.dy_scale.copy_(gt.expand(16))
+            eng.scale_buffer().copy_(gt.expand(16))
         else:
-            z = eng.plan.dy_scale.new_zeros(())
+            z = eng.scale_buffer().new_zeros(())
             gs = [(g if g is not None else z) + (gt if gt is not None else z) for g in (g0, g1, g2, g3)]
-            eng.plan.dy_scale.copy_(torch.stack([gs[0]] + [gs[1]] * 4 + [gs[2]] + [gs[3]] * 10))
+            eng.scale_buffer().copy_(torch.stack([gs[0]] + [gs[1]] * 4 + [gs[2]] + [gs[3]] * 10))
         eng.backward()                      # kernels + (world > 1) the bucketed gradient all-reduce
         model._after_backward()
         return None, None, None
