@@ -203,6 +203,22 @@ int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,
                  int32_t* labels, float* max_overlaps, float* img_stats, float* scratch,
                  void* stream);
 
+/* SimOTAAssigner's constructor arguments (sim_ota_assigner.py:25-33; ABI 6 -- rounds 1-3 compiled 10 / 3.0 / 1.0 in):
+ * cost = cls_cost * cls_weight + iou_cost * iou_weight (+1e5 outside box-and-centre); dynamic k from the
+ * candidate_topk largest IoUs (1 <= candidate_topk <= 16; the per-lane lists are compiled for 10 and for 16). */
+typedef struct YunetAssignCfg {
+    float center_radius;
+    int32_t candidate_topk;
+    float iou_weight, cls_weight;
+} YunetAssignCfg;
+/* yunet_assign_ex with explicit assigner parameters; in an op list YUNET_OP_ASSIGN reads f[0] = center_radius,
+ * i[3] = candidate_topk (0: 10), f[1] = iou_weight, f[2] = cls_weight (both 0: 3.0 / 1.0). */
+int yunet_assign_cfg(const float* flat, const float* pre_scores, const float* pre_boxes,
+                     const float* gt_boxes, const float* gt_kps, const int32_t* gt_labels,
+                     const int32_t* gt_count, const YunetLevels* lv, int N, int P, int Gmax,
+                     const YunetAssignCfg* cfg, int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                     float* img_stats, float* scratch, void* stream);
+
 /* Same kernel driven through SimOTAAssigner.assign()'s own signature
  * (sim_ota_assigner.py:38-93): pred_scores [N,P] = sigmoid(cls)*sigmoid(obj) and
  * decoded_bboxes [N,P,4] are given instead of being derived from `flat` (flat may be NULL). */

@@ -52,6 +52,11 @@ class YunetLossCfg(C.Structure):
                 ('smooth_point', C.c_float), ('kps_beta', C.c_float), ('defer_num_total', C.c_int32)]
 
 
+class YunetAssignCfg(C.Structure):
+    _fields_ = [('center_radius', C.c_float), ('candidate_topk', C.c_int32), ('iou_weight', C.c_float),
+                ('cls_weight', C.c_float)]
+
+
 class YunetAugCfg(C.Structure):
     _fields_ = [('out_size', C.c_int32), ('n_choice', C.c_int32), ('crop_choice', C.c_double * 8),
                 ('flip_ratio', C.c_double), ('pad_value', C.c_float), ('seed', C.c_uint32),
@@ -104,6 +109,8 @@ _SIGNATURES = {
                      [C.c_float] + [C.c_void_p] * 6),
     'yunet_assign_ex': (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +
                         [C.c_float] + [C.c_void_p] * 6),
+    'yunet_assign_cfg': (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YunetLevels)] + [C.c_int] * 3 +
+                         [C.POINTER(YunetAssignCfg)] + [C.c_void_p] * 6),
     'yunet_loss_norm': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'yunet_loss': (C.c_int, [C.c_void_p] * 5 + [C.POINTER(YunetLevels), C.POINTER(YunetLossCfg),
                                                 C.c_void_p] + [C.c_int] * 3 +

@@ -234,12 +234,15 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
             case YUNET_OP_REDUCE_BATCH:
                 rc = yunet_reduce_partials_batch((const YunetReduceJob*)o.p[0], o.i[0], o.i[1], stream);
                 break;
-            case YUNET_OP_ASSIGN:
-                rc = yunet_assign((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
-                                  (const int32_t*)o.p[3], (const int32_t*)o.p[4], &o.lv, o.i[0], o.i[1],
-                                  o.i[2], o.f[0], (int32_t*)o.p[5], (int32_t*)o.p[6], (float*)o.p[7],
-                                  (float*)o.p[8], (float*)o.p[9], stream);
+            case YUNET_OP_ASSIGN: {
+                const bool dflt = o.f[1] == 0.0f && o.f[2] == 0.0f;
+                const YunetAssignCfg ac{o.f[0], o.i[3] ? o.i[3] : 10, dflt ? 3.0f : o.f[1], dflt ? 1.0f : o.f[2]};
+                rc = yunet_assign_cfg((const float*)o.p[0], nullptr, nullptr, (const float*)o.p[1], (const float*)o.p[2],
+                                      (const int32_t*)o.p[3], (const int32_t*)o.p[4], &o.lv, o.i[0], o.i[1],
+                                      o.i[2], &ac, (int32_t*)o.p[5], (int32_t*)o.p[6], (float*)o.p[7],
+                                      (float*)o.p[8], (float*)o.p[9], stream);
                 break;
+            }
             case YUNET_OP_LOSS_NORM:
                 rc = yunet_loss_norm((const float*)o.p[0], o.i[0], o.f[0], (float*)o.p[1], stream);
                 break;

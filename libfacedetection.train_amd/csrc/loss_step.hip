@@ -15,7 +15,9 @@
 
 #define ASSIGN_THREADS 1024
 #define ASSIGN_WAVES (ASSIGN_THREADS / 64)
-#define TOPK 10
+// candidate_topk of SimOTAAssigner: the per-lane lists of assign_topk_kernel are compiled for 10 (the shipped
+// configs) and 16 entries; candidate_topk itself is a runtime argument <= the capacity
+#define TOPK_MAX 16
 #define INF_COST 100000.0f
 
 namespace {
@@ -52,10 +54,13 @@ __device__ __forceinline__ bool in_gt_center(float cx, float cy, float s, float 
     return fminf(fminf(l, t), fminf(r, b)) > 0.0f;
 }
 
-// cost[v,g] = (cls_cost*1.0 + iou_cost*3.0) + (in_both ? 0 : 1e5)
-__device__ __forceinline__ float cost_of(float cls_cost, float iou, bool in_both) {
+// cost[v,g] = (cls_cost*cls_weight + iou_cost*iou_weight) + (in_both ? 0 : 1e5)   (sim_ota_assigner.py:124-128)
+struct CostW {
+    float iou_w, cls_w;
+};
+__device__ __forceinline__ float cost_of(float cls_cost, float iou, bool in_both, CostW w) {
     float iou_cost = -logf(iou + 1e-7f);
-    float c = cls_cost * 1.0f + iou_cost * 3.0f;
+    float c = cls_cost * w.cls_w + iou_cost * w.iou_w;
     return c + (in_both ? 0.0f : INF_COST);
 }
 
@@ -208,9 +213,10 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_compact_kernel(
 
 // ---- B: one wave per (image, GT): dynamic k from the top-10 IoUs, then the k cheapest -------------------
 #define TOPK_WAVES 4
+template <int TOPK>
 __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
     const float* __restrict__ gt_boxes, const int32_t* __restrict__ gt_count, int P, int Gmax, int gblocks,
-    float radius, AssignScratch ws) {
+    float radius, int topk, CostW cw, AssignScratch ws) {
     const int n = blockIdx.x / gblocks;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = (blockIdx.x - n * gblocks) * TOPK_WAVES + wid;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
         const VRec r = rec[v];
         float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
         const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
-        float c = cost_of(r.cls_cost, iou, both);
+        float c = cost_of(r.cls_cost, iou, both, cw);
         int cv = v;
         if (iou > ti[TOPK - 1]) {
 #pragma unroll
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
     }
     // merge: sum of the wave-wide top-10 IoUs in descending order
     float sum = 0.0f;
-    const int K = V < TOPK ? V : TOPK;
+    const int K = V < topk ? V : topk;         // candidate_topk = min(self.candidate_topk, ious.size(0))
     for (int k = 0; k < K; ++k) {
         const float m = wave_max_f(ti[0]);
         const unsigned long long who = __ballot(ti[0] == m);
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
     }
     int dk = (int)sum;  // .int(): truncation toward zero
     dk = dk < 1 ? 1 : dk;
-    // at most TOPK IoUs <= 1 were added, so dk <= TOPK for finite predictions.  A diverged model (inf / NaN boxes)
+    // at most candidate_topk IoUs <= 1 were added, so dk <= candidate_topk for finite predictions.  A diverged model (inf / NaN boxes)
     // can make the sum inf and (int)inf = INT_MAX: bound the loop so that a diverged run reports NaN losses, as the
     // reference does, instead of spinning for 2^31 iterations per (image, GT) pair
-    dk = dk > TOPK ? TOPK : dk;
+    dk = dk > topk ? topk : dk;
     for (int k = 0; k < dk; ++k) {
         const unsigned long long key = ((unsigned long long)ord(tc[0]) << 32) | (uint32_t)tv[0];
         const unsigned long long kmin = wave_min_u64(key);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
 // ---- C: conflicts -> argmin over ALL gts; outputs; per-image statistics (one workgroup per image) -------
 __global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve_kernel(
     const float* __restrict__ gt_boxes, const float* __restrict__ gt_kps, const int32_t* __restrict__ gt_labels,
-    const int32_t* __restrict__ gt_count, int P, int Gmax, float radius, int32_t* __restrict__ gt_inds,
+    const int32_t* __restrict__ gt_count, int P, int Gmax, float radius, CostW cw, int32_t* __restrict__ gt_inds,
     int32_t* __restrict__ labels, float* __restrict__ max_overlaps, float* __restrict__ img_stats,
     AssignScratch ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve_kernel(
                 const GT gt = s_gt[j];
                 const float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
                 const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
-                const float cj = cost_of(r.cls_cost, iou, both);
+                const float cj = cost_of(r.cls_cost, iou, both, cw);
                 if (cj < best) {
                     best = cj;
                     g = j;
@@ -624,15 +630,18 @@ extern "C" int yunet_loss_blocks(int N, int P) {
     return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
 }
 
-extern "C" int yunet_assign_ex(const float* flat, const float* pre_scores, const float* pre_boxes,
-                               const float* gt_boxes, const float* gt_kps,
-                               const int32_t* gt_labels, const int32_t* gt_count,
-                               const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
-                               int32_t* gt_inds, int32_t* labels, float* max_overlaps,
-                               float* img_stats, float* scratch, void* stream) {
+extern "C" int yunet_assign_cfg(const float* flat, const float* pre_scores, const float* pre_boxes,
+                                const float* gt_boxes, const float* gt_kps,
+                                const int32_t* gt_labels, const int32_t* gt_count,
+                                const YunetLevels* lv, int N, int P, int Gmax, const YunetAssignCfg* cfg,
+                                int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                                float* img_stats, float* scratch, void* stream) {
     if (!lv || lv->num_levels < 1 || lv->num_levels > YUNET_MAX_LEVELS || P > 65535 || N < 1 ||
-        Gmax < 1)
+        Gmax < 1 || !cfg || cfg->candidate_topk < 1 || cfg->candidate_topk > TOPK_MAX)
         return YUNET_EINVAL;
+    const float center_radius = cfg->center_radius;
+    const int topk = cfg->candidate_topk;
+    const CostW cw{cfg->iou_weight, cfg->cls_weight};
     Levels L = make_levels(lv);
     if (L.base[YUNET_MAX_LEVELS] != P) return YUNET_EINVAL;
     const size_t lds = (size_t)Gmax * sizeof(GT);
@@ -642,11 +651,26 @@ extern "C" int yunet_assign_ex(const float* flat, const float* pre_scores, const
     hipLaunchKernelGGL(assign_compact_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, st, flat, gt_boxes, gt_count, L, P,
                        Gmax, center_radius, gt_inds, labels, max_overlaps, ws, pre_scores, pre_boxes);
     const int gblocks = (Gmax + TOPK_WAVES - 1) / TOPK_WAVES;
-    hipLaunchKernelGGL(assign_topk_kernel, dim3(N * gblocks), dim3(TOPK_WAVES * 64), 0, st, gt_boxes, gt_count, P, Gmax,
-                       gblocks, center_radius, ws);
+    if (topk <= 10)
+        hipLaunchKernelGGL(assign_topk_kernel<10>, dim3(N * gblocks), dim3(TOPK_WAVES * 64), 0, st, gt_boxes, gt_count, P,
+                           Gmax, gblocks, center_radius, topk, cw, ws);
+    else
+        hipLaunchKernelGGL(assign_topk_kernel<TOPK_MAX>, dim3(N * gblocks), dim3(TOPK_WAVES * 64), 0, st, gt_boxes, gt_count,
+                           P, Gmax, gblocks, center_radius, topk, cw, ws);
     hipLaunchKernelGGL(assign_resolve_kernel, dim3(N), dim3(ASSIGN_THREADS), lds, st, gt_boxes, gt_kps, gt_labels,
-                       gt_count, P, Gmax, center_radius, gt_inds, labels, max_overlaps, img_stats, ws);
+                       gt_count, P, Gmax, center_radius, cw, gt_inds, labels, max_overlaps, img_stats, ws);
     return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_assign_ex(const float* flat, const float* pre_scores, const float* pre_boxes,
+                               const float* gt_boxes, const float* gt_kps,
+                               const int32_t* gt_labels, const int32_t* gt_count,
+                               const YunetLevels* lv, int N, int P, int Gmax, float center_radius,
+                               int32_t* gt_inds, int32_t* labels, float* max_overlaps,
+                               float* img_stats, float* scratch, void* stream) {
+    const YunetAssignCfg cfg{center_radius, 10, 3.0f, 1.0f};      // SimOTAAssigner's defaults (configs/yunet_*.py)
+    return yunet_assign_cfg(flat, pre_scores, pre_boxes, gt_boxes, gt_kps, gt_labels, gt_count, lv, N, P, Gmax, &cfg,
+                            gt_inds, labels, max_overlaps, img_stats, scratch, stream);
 }
 
 extern "C" int yunet_assign(const float* flat, const float* gt_boxes, const float* gt_kps,

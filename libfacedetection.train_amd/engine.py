@@ -351,7 +351,8 @@ class Plan:
                          None, self.gt_count.data_ptr(), self.gt_inds.data_ptr(), None,
                          self.max_overlaps.data_ptr(), self.img_stats.data_ptr(),
                          self.scratch.data_ptr()],
-                      i=[n, self.P, gmax], f=[arch['center_radius']])
+                      i=[n, self.P, gmax, int(arch.get('candidate_topk', 10))],
+                      f=[arch['center_radius'], float(arch.get('iou_weight', 3.0)), float(arch.get('cls_weight', 1.0))])
         op.lv = self.levels
         self.fwd_a.append(op)
         self.fwd_a.append(self._op(L.OP_LOSS_NORM, p=[self.img_stats.data_ptr(),

@@ -311,9 +311,10 @@ def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.
 
 
 def assign(flat, gt_boxes, gt_kps, gt_count, sizes, strides, center_radius=2.5, gt_labels=None,
-           want_labels=False, pre_scores=None, pre_boxes=None):
+           want_labels=False, pre_scores=None, pre_boxes=None, candidate_topk=10, iou_weight=3.0, cls_weight=1.0):
     """flat [N,P,16]; gt_boxes [N,Gmax,4]; gt_kps [N,Gmax,5,3]; gt_count [N] int32.
-    -> gt_inds [N,P] int32, max_overlaps [N,P], img_stats [N,2], labels or None."""
+    -> gt_inds [N,P] int32, max_overlaps [N,P], img_stats [N,2], labels or None.
+    candidate_topk / iou_weight / cls_weight: SimOTAAssigner's constructor arguments (1 <= candidate_topk <= 16)."""
     _chk_f32(flat, gt_boxes, gt_kps, pre_scores, pre_boxes)
     n, p = (flat.shape[0], flat.shape[1]) if flat is not None else pre_scores.shape
     gmax = gt_boxes.shape[1]
@@ -324,10 +325,11 @@ def assign(flat, gt_boxes, gt_kps, gt_count, sizes, strides, center_radius=2.5, 
     img_stats = torch.empty(n, 2, device=dev, dtype=torch.float32)
     scratch = torch.empty(n, p, 12, device=dev, dtype=torch.float32)
     lv = make_levels(sizes, strides)
-    L.check(L.load().yunet_assign_ex(_p(flat), _p(pre_scores), _p(pre_boxes), _p(gt_boxes),
-                                     _p(gt_kps), _p(gt_labels), _p(gt_count), C.byref(lv), n, p,
-                                     gmax, float(center_radius), _p(gt_inds), _p(labels), _p(ovl),
-                                     _p(img_stats), _p(scratch), _stream()), 'yunet_assign')
+    cfg = L.YunetAssignCfg(float(center_radius), int(candidate_topk), float(iou_weight), float(cls_weight))
+    L.check(L.load().yunet_assign_cfg(_p(flat), _p(pre_scores), _p(pre_boxes), _p(gt_boxes),
+                                      _p(gt_kps), _p(gt_labels), _p(gt_count), C.byref(lv), n, p,
+                                      gmax, C.byref(cfg), _p(gt_inds), _p(labels), _p(ovl),
+                                      _p(img_stats), _p(scratch), _stream()), 'yunet_assign')
     return gt_inds, ovl, img_stats, labels
 
 

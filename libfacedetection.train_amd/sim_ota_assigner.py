@@ -24,9 +24,8 @@ class AssignResult:
 @BBOX_ASSIGNERS.register_module()
 class SimOTAAssigner:
     def __init__(self, center_radius=2.5, candidate_topk=10, iou_weight=3.0, cls_weight=1.0):
-        if candidate_topk != 10 or iou_weight != 3.0 or cls_weight != 1.0:
-            raise NotImplementedError('the HIP kernel is specialised for candidate_topk=10, '
-                                      'iou_weight=3.0, cls_weight=1.0 (the shipped configs)')
+        if not 1 <= int(candidate_topk) <= 16:
+            raise NotImplementedError('candidate_topk must be in 1..16 (per-lane candidate lists of the HIP kernel)')
         self.center_radius = center_radius
         self.candidate_topk, self.iou_weight, self.cls_weight = candidate_topk, iou_weight, cls_weight
 
@@ -60,7 +59,8 @@ class SimOTAAssigner:
         gi, ovl, _, labels = K.assign(
             None, gb, gk, cnt, sizes, strides, self.center_radius, gt_labels=gl, want_labels=True,
             pre_scores=pred_scores.reshape(1, P).float().contiguous(),
-            pre_boxes=decoded_bboxes.reshape(1, P, 4).float().contiguous())
+            pre_boxes=decoded_bboxes.reshape(1, P, 4).float().contiguous(),
+            candidate_topk=self.candidate_topk, iou_weight=self.iou_weight, cls_weight=self.cls_weight)
         if G == 0:
             ovl = torch.zeros_like(ovl)      # sim_ota_assigner.py:136-149
         return AssignResult(G, gi[0].long(), ovl[0], labels=labels[0].long())

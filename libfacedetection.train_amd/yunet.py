@@ -240,7 +240,9 @@ class YuNet(nn.Module):
             loss_bbox=type(hd.loss_bbox).__name__, loss_bbox_weight=hd.loss_bbox.loss_weight,
             loss_cls_weight=hd.loss_cls.loss_weight, loss_obj_weight=hd.loss_obj.loss_weight,
             loss_kps_weight=hd.loss_kps.loss_weight, kps_beta=hd.loss_kps.beta,
-            center_radius=hd.assigner.center_radius if hd.assigner is not None else 2.5)
+            center_radius=hd.assigner.center_radius if hd.assigner is not None else 2.5,
+            candidate_topk=getattr(hd.assigner, 'candidate_topk', 10), iou_weight=getattr(hd.assigner, 'iou_weight', 3.0),
+            cls_weight=getattr(hd.assigner, 'cls_weight', 1.0))
 
     def set_precision(self, precision):
         """'fp32' (default) or 'bf16': bf16 activation storage + bf16 matrix instruction in the forward

@@ -38,7 +38,9 @@ class _LossStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, gb, gk, cnt, sizes, strides, cfg, radius, world, group):
-        gi, ovl, img_stats, _ = K.assign(flat, gb, gk, cnt, sizes, strides, radius)
+        rad, topk, iou_w, cls_w = radius if isinstance(radius, tuple) else (radius, 10, 3.0, 1.0)
+        gi, ovl, img_stats, _ = K.assign(flat, gb, gk, cnt, sizes, strides, rad, candidate_topk=topk, iou_weight=iou_w,
+                                         cls_weight=cls_w)
         norm = None
         if world > 1:
             # reduce_mean(num_pos) (yunet_head.py:493-497): norm[0] = local/world, SUM over ranks
@@ -177,7 +179,8 @@ class YuNet_Head(nn.Module):
         gb, gk, cnt = pad_gt(gt_bboxes, gt_kpss, flat.device)
         world = torch.distributed.get_world_size() if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
-        radius = self.assigner.center_radius if self.assigner is not None else 2.5
+        a = self.assigner            # SimOTAAssigner(center_radius, candidate_topk, iou_weight, cls_weight)
+        radius = (a.center_radius, a.candidate_topk, a.iou_weight, a.cls_weight) if a is not None else 2.5
         l_cls, l_box, l_obj, l_kps, gi = _LossStep.apply(
             flat, gb, gk, cnt, sizes, self.strides, self.loss_cfg(), radius, world, None)
         self.last_gt_inds = gi

@@ -52,6 +52,9 @@ def arch_from_model_cfg(model_cfg):
         loss_kps_weight=hd['loss_kps'].get('loss_weight', 1.0),
         kps_beta=hd['loss_kps'].get('beta', 1.0),
         center_radius=model_cfg['train_cfg']['assigner'].get('center_radius', 2.5),
+        candidate_topk=model_cfg['train_cfg']['assigner'].get('candidate_topk', 10),
+        iou_weight=model_cfg['train_cfg']['assigner'].get('iou_weight', 3.0),
+        cls_weight=model_cfg['train_cfg']['assigner'].get('cls_weight', 1.0),
     )
 
 
@@ -70,7 +73,7 @@ def yunet_arch(kind='n', loss_bbox='EIoULoss'):
                 shared_stacked_convs=shared, stacked_convs=0, kps_num=5,
                 strides=[8, 16, 32], loss_bbox=loss_bbox, loss_bbox_weight=5.0,
                 loss_cls_weight=1.0, loss_obj_weight=1.0, loss_kps_weight=0.1,
-                kps_beta=0.1111111111111111, center_radius=2.5)
+                kps_beta=0.1111111111111111, center_radius=2.5, candidate_topk=10, iou_weight=3.0, cls_weight=1.0)
 
 
 def dp_units(arch):
@@ -405,7 +408,9 @@ def loss_step(flat, gt_bboxes, gt_labels, gt_kpss, featmap_sizes, arch, world_me
             gk = gt_kpss[n].to(torch.float32)
             score = cls[n].detach().sigmoid() * obj[n].detach().sigmoid()
             gi, _, ovl = simota_assign(score, offset_priors, decoded[n].detach(), gb,
-                                       gt_labels[n], center_radius=arch['center_radius'])
+                                       gt_labels[n], center_radius=arch['center_radius'],
+                                       candidate_topk=arch.get('candidate_topk', 10), iou_weight=arch.get('iou_weight', 3.0),
+                                       cls_weight=arch.get('cls_weight', 1.0))
             pos = torch.nonzero(gi > 0).squeeze(1)          # ascending (pseudo_sampler.py:35)
             mg = gi[pos] - 1
             all_gt_inds.append(gi)

@@ -45,8 +45,11 @@ def test_registry_names_and_errors():
         yunet_amd.build_detector(dict(type='NoSuchDetector'))
     with pytest.raises(TypeError):
         yunet_amd.build_from_cfg(dict(foo=1), yunet_amd.MODELS)
+    # round 4: SimOTAAssigner takes the reference's constructor arguments (candidate_topk up to 16)
+    a = yunet_amd.build_assigner(dict(type='SimOTAAssigner', candidate_topk=5, iou_weight=2.0, cls_weight=0.5))
+    assert (a.candidate_topk, a.iou_weight, a.cls_weight, a.center_radius) == (5, 2.0, 0.5, 2.5)
     with pytest.raises(NotImplementedError):
-        yunet_amd.build_assigner(dict(type='SimOTAAssigner', candidate_topk=5))
+        yunet_amd.build_assigner(dict(type='SimOTAAssigner', candidate_topk=17))
     m, _ = build('s')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m.forward_train(torch.zeros(1, 3, 160, 160), [{}], [torch.zeros(1, 4)], [torch.zeros(1)],
