@@ -47,34 +47,25 @@ python $GRAFT_REPO_ROOT/tools/pmc_mean.py $OUT/${R}_util.json $UT
 cd $GRAFT_REPO_ROOT
 timeout 300 python bench.py --dtype bf16 --steps 30 --warmup 10 --no-cpu-baseline --no-gpu-eager 2>/dev/null | tail -1 > $OUT/${R}_bench_bf16.json
 #   6. torch-free kernel A/B at sustained clocks (tools/ubench/bwd_ab), every variant a copy of THIS library (the
-#      environment switches are read once per library instance): the exact-fp32 matrix path (= the yardstick), the
-#      round-2 split-bf16 kernel (YUNET_BWD64_R2), this round's dp_bwd64 with 8 waves / 8 x 16 tiles and with
+#      environment switches are read once per library instance): the exact-fp32 matrix path (= the yardstick),
+#      dp_bwd64 with 8 waves / 8 x 16 tiles and with
 #      4 waves / 8 x 8 tiles, and the dispatch default; then forward + backward with one and with eight replicas
 #      of the BatchNorm sum blocks (SLOTS, YunetBN::slots: the end-of-kernel atomics of the small levels)
-for v in fp32 r2k nw8 nw4; do cp libfacedetection.train_amd/libyunet_hip.so /tmp/libyunet_$v.so; done
-REPS=1000 timeout 300 tools/ubench/bwd_ab.bin /tmp/libyunet_fp32.so:YUNET_BWD_FP32MMA=1 /tmp/libyunet_r2k.so:YUNET_BWD64_R2=1 \
+for v in fp32 nw8 nw4 tile; do cp libfacedetection.train_amd/libyunet_hip.so /tmp/libyunet_$v.so; done
+REPS=1000 timeout 300 tools/ubench/bwd_ab.bin /tmp/libyunet_fp32.so:YUNET_BWD_FP32MMA=1 \
     /tmp/libyunet_nw8.so:YUNET_BWD64_NW=8 /tmp/libyunet_nw4.so:YUNET_BWD64_NW=4 libfacedetection.train_amd/libyunet_hip.so \
     > $OUT/${R}_bwd_ab.log 2>&1
-SHAPES_ALL=1 ONLY=160 REPS=300 timeout 200 tools/ubench/bwd_ab.bin /tmp/libyunet_r2k.so:YUNET_BWD64_R2=1 libfacedetection.train_amd/libyunet_hip.so \
+SHAPES_ALL=1 ONLY=160 REPS=300 timeout 200 tools/ubench/bwd_ab.bin /tmp/libyunet_fp32.so:YUNET_BWD_FP32MMA=1 libfacedetection.train_amd/libyunet_hip.so \
     >> $OUT/${R}_bwd_ab.log 2>&1
-for sl in 1 8; do
+echo "== forward 64->64: tile kernel (YUNET_FWD64S=0) vs the wave-streaming kernel (default)" >> $OUT/${R}_bwd_ab.log
+SLOTS=8 FWD=1 REPS=500 timeout 200 tools/ubench/bwd_ab.bin /tmp/libyunet_tile.so:YUNET_FWD64S=0 libfacedetection.train_amd/libyunet_hip.so \
+    >> $OUT/${R}_bwd_ab.log 2>&1
+for sl in 8; do
   echo "== SLOTS=$sl (forward, then backward)" >> $OUT/${R}_bwd_ab.log
   SLOTS=$sl FWD=1 REPS=500 timeout 200 tools/ubench/bwd_ab.bin /tmp/libyunet_fp32.so libfacedetection.train_amd/libyunet_hip.so 2>&1 \
       | grep -v yardstick >> $OUT/${R}_bwd_ab.log
   SLOTS=$sl REPS=500 timeout 200 tools/ubench/bwd_ab.bin /tmp/libyunet_fp32.so:YUNET_BWD_FP32MMA=1 libfacedetection.train_amd/libyunet_hip.so 2>&1 \
       | grep -v yardstick | grep -v "max|" >> $OUT/${R}_bwd_ab.log
-done
-#   6b. queued forward-kernel variants (built by tools/ubench/build_ab.sh NAME "FLAGS"; each prints z / BN-sum errors
-#       against the product library next to its time): ilv = "-DYUNET_FWD_MFMA_INTERLEAVE=1 -DYUNET_BWD_MFMA_INTERLEAVE=1",
-#       pk = "-DYUNET_FWD_PK_STAGE=1"
-for v in ilv pk; do
-  if [ -f tools/ubench/libyunet_$v.so ]; then
-    echo "== variant $v: forward, then backward (product, variant, product, variant)" >> $OUT/${R}_bwd_ab.log
-    SLOTS=8 FWD=1 REPS=500 timeout 200 tools/ubench/bwd_ab.bin libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so \
-        libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so >> $OUT/${R}_bwd_ab.log 2>&1
-    SLOTS=8 REPS=500 timeout 200 tools/ubench/bwd_ab.bin libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so \
-        libfacedetection.train_amd/libyunet_hip.so tools/ubench/libyunet_$v.so 2>&1 | grep -v "max|" >> $OUT/${R}_bwd_ab.log
-  fi
 done
 #   7. per-phase cycle counters of dp_bwd64 (a -DDP_BWD_PROF build made by tools/ubench/build_ab.sh prof "-DDP_BWD_PROF"),
 #      whole kernel and with every GEMM / depthwise phase and the global traffic ablated (ABL=63: what staging costs)
