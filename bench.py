@@ -274,8 +274,9 @@ def op_name(op, L):
             gemm += ',true' if full else ',false'
         else:
             # round 4: the plain fp32 64 -> 64 forward unit runs on the wave-streaming kernel (csrc/conv_fwd64.hip)
-            if (d.cin == 64 and d.cout == 64 and not packed and d.x_dtype == L.F32
-                    and os.environ.get('YUNET_FWD64S', '1') != '0'):
+            # (since the small-level measurement also on the 20 x 20 / 10 x 10 levels unless YUNET_FWD64S=1)
+            f64s = int(os.environ.get('YUNET_FWD64S', '2'))
+            if d.cin == 64 and d.cout == 64 and d.x_dtype == L.F32 and f64s >= (2 if packed else 1):
                 return 'dp_fwd64s_kernel<true>' if d.pool_out else 'dp_fwd64s_kernel<false>'
             gemm = ',true' if d.pool_out else ',false'      # forward: fused pooling outputs
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"

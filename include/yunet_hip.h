@@ -3,7 +3,8 @@
  * training hot path.  Plain pointers and sizes only: every pointer is a DEVICE pointer
  * unless stated otherwise, `stream` is a hipStream_t passed as void*, every function
  * returns 0 on success or a negative YUNET_E* / the hipError_t of the failed launch.
- * No ownership is transferred; nothing is allocated; nothing synchronises.
+ * No ownership is transferred; nothing is allocated; nothing synchronises (the inbox set-up of the
+ * one-shot all-reduce at the end of this file is the one exception, and says so).
  *
  * The reference (ShiqiYu/libfacedetection.train) has no FFI: its drop-in boundary is
  * the mmcv Registry.  The registered Python classes of
@@ -24,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 6
+#define YUNET_ABI_VERSION 7
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -397,9 +398,46 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "bwd64_nw"           0 (by shape) | 4 | 8: waves per workgroup of the 64 -> 64 backward kernel
  *   "ew_grid"            workgroup cap of the element-wise backward kernels (0 restores the default, 768)
  *   "fwd_blocks_per_cu"  0 (occupancy API) | 1..4: resident forward workgroups per CU
+ *   "fwd64s"             0: every fp32 64 -> 64 forward unit on the tile kernel | 1: the plain and fused-pooling units on
+ *                        the wave-streaming kernel | 2 (default): the 20x20 / 10x10 levels too
+ *   "fwd64s_rows"        0 (by shape) | rows per band of the wave-streaming kernel
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
 int yunet_set_option(const char* name, int value);
+
+/* ---- gradient / num_pos exchange between the GPUs of one node (csrc/collective.hip) ---------------------
+ * Replaces, for this path, what the reference gets from torch DDP over NCCL (mmdet/apis/train.py:152-163:
+ * MMDistributedDataParallel averages the ~300 KB of gradients) and from reduce_mean
+ * (mmdet/core/utils/dist_utils.py:68-74, called at yunet_head.py:493-497 for num_pos).  The messages are
+ * latency-bound and xGMI is a point-to-point mesh, so instead of a ring every rank STORES its message into a
+ * slot of every peer's inbox (peer-mapped device memory), raises a flag behind it, waits for the world's flags
+ * in its own inbox and adds the slots in rank order: one kernel per rank, results bit-identical on all ranks.
+ *
+ * These are the only entry points that allocate: an inbox is uncached device memory that peers map through
+ * hipIpc* handles (one process per GPU).  Set-up, per rank: yunet_comm_alloc -> yunet_comm_export -> exchange the
+ * 64-byte handles over any host channel -> yunet_comm_open on every peer's handle -> fill a YunetComm.
+ * Every rank must issue the same sequence of yunet_allreduce calls on a given YunetComm (one YunetComm per stream
+ * that carries collectives).  A peer that never arrives makes the wait give up after ~3 s: the buffer is left
+ * untouched and yunet_comm_status() returns the sequence number of that call. */
+#define YUNET_MAX_RANKS 8
+#define YUNET_IPC_HANDLE_BYTES 64
+typedef struct YunetComm {
+    int32_t rank, world;
+    uint32_t seq;                    /* calls made so far; incremented by yunet_allreduce (start at 0)          */
+    int32_t reserved_;
+    uint64_t slot_bytes;             /* capacity of one message: (inbox bytes - 4096) / (2 * world)            */
+    void* inbox[YUNET_MAX_RANKS];    /* inbox of rank r as mapped into THIS process (own rank: the allocation) */
+    int32_t* status;                 /* HOST word from yunet_comm_alloc                                        */
+} YunetComm;
+size_t yunet_comm_inbox_bytes(int world, size_t max_msg_bytes);
+int yunet_comm_alloc(size_t bytes, void** inbox, int32_t** status);
+int yunet_comm_free(void* inbox, int32_t* status);
+int yunet_comm_export(void* inbox, void* handle64 /* HOST, YUNET_IPC_HANDLE_BYTES */);
+int yunet_comm_open(const void* handle64 /* HOST */, void** mapped);
+int yunet_comm_close(void* mapped);
+/* buf[0..n) <- sum over ranks (mean != 0: divided by world), in place, n * 4 <= slot_bytes. */
+int yunet_allreduce(YunetComm* c /* HOST */, float* buf, size_t n, int mean, void* stream);
+int yunet_comm_status(const YunetComm* c /* HOST */);
 
 int yunet_abi_version(void);
 /* grid size the fused conv kernels are launched with (rows of wgrad_partials). */

@@ -63,6 +63,14 @@ class YunetAugCfg(C.Structure):
                 ('max_attempts', C.c_int32), ('max_retries', C.c_int32), ('gmax', C.c_int32)]
 
 
+MAX_RANKS, IPC_HANDLE_BYTES = 8, 64
+
+
+class YunetComm(C.Structure):
+    _fields_ = [('rank', C.c_int32), ('world', C.c_int32), ('seq', C.c_uint32), ('reserved_', C.c_int32),
+                ('slot_bytes', C.c_uint64), ('inbox', C.c_void_p * MAX_RANKS), ('status', C.c_void_p)]
+
+
 class YunetOp(C.Structure):
     _fields_ = [('opcode', C.c_int32), ('i', C.c_int32 * 12), ('f', C.c_float * 8),
                 ('p', C.c_void_p * 12), ('bn', YunetBN * 2), ('dp', YunetDP),
@@ -122,6 +130,14 @@ _SIGNATURES = {
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
     'yunet_exec_lanes': (C.c_int, [C.c_int]),
     'yunet_set_option': (C.c_int, [C.c_char_p, C.c_int]),
+    'yunet_comm_inbox_bytes': (C.c_size_t, [C.c_int, C.c_size_t]),
+    'yunet_comm_alloc': (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    'yunet_comm_free': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'yunet_comm_export': (C.c_int, [C.c_void_p, C.c_char_p]),
+    'yunet_comm_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'yunet_comm_close': (C.c_int, [C.c_void_p]),
+    'yunet_allreduce': (C.c_int, [C.POINTER(YunetComm), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    'yunet_comm_status': (C.c_int, [C.POINTER(YunetComm)]),
 }
 for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
            'yunet_upadd_fwd', 'yunet_upadd_bwd'):
@@ -151,7 +167,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 6:
+    if lib.yunet_abi_version() != 7:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -92,7 +92,7 @@ YunetOptions& yunet_options() {
         v.bwd64_nw = env("YUNET_BWD64_NW", 0);
         v.ew_grid = env("YUNET_EW_GRID", 768);
         v.fwd_blocks_per_cu = env("YUNET_DP_FWD_BLOCKS_PER_CU", 0);
-        v.fwd64s = env("YUNET_FWD64S", 1);
+        v.fwd64s = env("YUNET_FWD64S", 2);
         v.fwd64s_rows = env("YUNET_FWD64S_ROWS", 0);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;

@@ -1,0 +1,200 @@
+// collective.hip -- one-shot all-reduce between the GPUs of ONE node over peer-mapped memory (xGMI stores).
+//
+// The reference averages gradients through torch DDP over NCCL (mmdet/apis/train.py:152-163) and reduces num_pos
+// with dist.all_reduce (mmdet/core/utils/dist_utils.py:68-74, yunet_head.py:493-497).  Here the messages are tiny
+// and latency-bound -- num_pos is 4 bytes, the exposed gradient bucket ~50 KB, the whole gradient ~300 KB -- and
+// xGMI is a full point-to-point mesh (7 links per GPU), so a ring (2 (N - 1) dependent hops) is the wrong shape:
+// every rank STORES its message into a slot of every peer's inbox, raises a flag behind it, waits for the world's
+// flags in its OWN inbox and adds the slots up in rank order.  One kernel per rank, one xGMI crossing per message,
+// bit-identical results on every rank (fixed summation order), no dependence on a communication library.
+//
+//   inbox of a rank (device memory of that rank, mapped into every peer by hipIpc*):
+//     [0, 2 KB)      flags[2 parities][YUNET_MAX_RANKS], one 128-byte line each: sequence number of the newest
+//                    message of rank r with that parity
+//     [2 KB, 4 KB)   local counter (blocks of this rank that finished sending; never touched by peers)
+//     [4 KB, ...)    slots[2 parities][world][slot_bytes]
+//   Messages alternate between the two parities: a rank can run at most one call ahead of a peer (it needs that
+//   peer's flag of call s to finish call s), so the slots of call s + 1 never overwrite data a peer still reads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/yunet_hip.h"
+
+namespace {
+constexpr size_t FLAG_STRIDE = 128, FLAGS_BYTES = 2 * YUNET_MAX_RANKS * FLAG_STRIDE;
+constexpr size_t CTR_OFF = FLAGS_BYTES, SLOTS_OFF = 4096;
+constexpr int AR_THREADS = 512;
+typedef float vf4 __attribute__((ext_vector_type(4)));
+constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;      // wall_clock64: 100 MHz -> 3 s
+
+struct ARArgs {
+    unsigned char* inbox[YUNET_MAX_RANKS];
+    int32_t* status;
+    float* buf;
+    unsigned long long n;
+    unsigned long long slot_bytes;
+    unsigned seq;
+    int rank, world;
+    float scale;
+};
+
+__device__ __forceinline__ unsigned* flag_ptr(unsigned char* inbox, int parity, int r) {
+    return reinterpret_cast<unsigned*>(inbox + (size_t)(parity * YUNET_MAX_RANKS + r) * FLAG_STRIDE);
+}
+
+// block b sends this rank's message to peer b, then every block reduces a share of the elements
+__global__ __launch_bounds__(AR_THREADS) void oneshot_allreduce_kernel(const ARArgs a) {
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int parity = a.seq & 1;
+    const size_t n = a.n;
+    // ---- send: buf -> slot [parity][rank] of peer p (16-byte stores; the tail in floats)
+    {
+        float* dst = reinterpret_cast<float*>(a.inbox[p] + SLOTS_OFF + ((size_t)parity * a.world + a.rank) * a.slot_bytes);
+        const size_t n4 = (reinterpret_cast<uintptr_t>(a.buf) & 15) == 0 ? n / 4 : 0;
+        const float4* s4 = reinterpret_cast<const float4*>(a.buf);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (size_t i = tid; i < n4; i += AR_THREADS) d4[i] = s4[i];
+        for (size_t i = n4 * 4 + tid; i < n; i += AR_THREADS) dst[i] = a.buf[i];
+    }
+    __threadfence_system();          // the message is visible to the peer before its flag
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(flag_ptr(a.inbox[p], parity, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // buf may be overwritten (below) only after EVERY block of this rank has sent it
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a.inbox[a.rank] + CTR_OFF), 1ull, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- wait: the world's messages with this sequence number are in OUR inbox; all our blocks have sent
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid <= a.world) {
+        const unsigned long long t0 = wall_clock64();
+        bool ok = false;
+        while (!ok) {
+            if (tid < a.world)
+                ok = __hip_atomic_load(flag_ptr(a.inbox[a.rank], parity, tid), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == a.seq;
+            else
+                ok = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.inbox[a.rank] + CTR_OFF), __ATOMIC_ACQUIRE,
+                                       __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)a.seq * (unsigned)a.world;
+            if (!ok) {
+                if (wall_clock64() - t0 > TIMEOUT_TICKS) { s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) {                    // a peer never arrived: leave buf alone, tell the host which call it was
+        if (tid == 0 && a.status) *reinterpret_cast<volatile int32_t*>(a.status) = (int32_t)a.seq;
+        return;
+    }
+    __threadfence_system();
+    // ---- reduce: block p owns elements [p * share, (p + 1) * share), slots added in rank order
+    const unsigned char* slots = a.inbox[a.rank] + SLOTS_OFF + (size_t)parity * a.world * a.slot_bytes;
+    const size_t share = ((n + (size_t)a.world * 4 - 1) / ((size_t)a.world * 4)) * 4;
+    const size_t lo = (size_t)p * share, hi = lo + share < n ? lo + share : n;
+    const bool vec = (reinterpret_cast<uintptr_t>(a.buf) & 15) == 0;
+    if (vec) {
+        const size_t hi4 = lo + ((hi > lo ? hi - lo : 0) / 4) * 4;
+        for (size_t i = lo + 4 * (size_t)tid; i < hi4; i += 4 * (size_t)AR_THREADS) {
+            vf4 acc = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(slots) + i / 4);
+            for (int r = 1; r < a.world; ++r)
+                acc += __builtin_nontemporal_load(reinterpret_cast<const vf4*>(slots + (size_t)r * a.slot_bytes) + i / 4);
+            *reinterpret_cast<vf4*>(a.buf + i) = acc * a.scale;
+        }
+        for (size_t i = hi4 + tid; i < hi; i += AR_THREADS) {
+            float acc = __builtin_nontemporal_load(reinterpret_cast<const float*>(slots) + i);
+            for (int r = 1; r < a.world; ++r)
+                acc += __builtin_nontemporal_load(reinterpret_cast<const float*>(slots + (size_t)r * a.slot_bytes) + i);
+            a.buf[i] = acc * a.scale;
+        }
+    } else {
+        for (size_t i = lo + tid; i < hi; i += AR_THREADS) {
+            float acc = __builtin_nontemporal_load(reinterpret_cast<const float*>(slots) + i);
+            for (int r = 1; r < a.world; ++r)
+                acc += __builtin_nontemporal_load(reinterpret_cast<const float*>(slots + (size_t)r * a.slot_bytes) + i);
+            a.buf[i] = acc * a.scale;
+        }
+    }
+}
+
+inline int st(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
+}  // namespace
+
+extern "C" size_t yunet_comm_inbox_bytes(int world, size_t max_msg_bytes) {
+    if (world < 1 || world > YUNET_MAX_RANKS || max_msg_bytes == 0) return 0;
+    const size_t slot = (max_msg_bytes + 255) & ~(size_t)255;
+    return SLOTS_OFF + 2 * (size_t)world * slot;
+}
+
+extern "C" int yunet_comm_alloc(size_t bytes, void** inbox, int32_t** status) {
+    if (!inbox || !status || bytes < SLOTS_OFF) return YUNET_EINVAL;
+    void* p = nullptr;
+    // uncached device memory: peers' stores and our polls go to memory, not through an L2 that is private to an XCD;
+    // plain hipMalloc as the fall-back (the kernel's system-scope release / acquire pairs are written for both)
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&p, bytes) != hipSuccess) return st(hipGetLastError());
+    }
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    int32_t* s = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s), 64, hipHostMallocMapped);
+    if (e != hipSuccess) { (void)hipFree(p); return st(e); }
+    *s = 0;
+    *inbox = p;
+    *status = s;
+    return 0;
+}
+
+extern "C" int yunet_comm_free(void* inbox, int32_t* status) {
+    int rc = 0;
+    if (inbox) rc = st(hipFree(inbox));
+    if (status) { const int r2 = st(hipHostFree(status)); if (!rc) rc = r2; }
+    return rc;
+}
+
+extern "C" int yunet_comm_export(void* inbox, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == YUNET_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    if (!inbox || !handle64) return YUNET_EINVAL;
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, inbox);
+    if (e != hipSuccess) return st(e);
+    memcpy(handle64, &h, sizeof(h));
+    return 0;
+}
+
+extern "C" int yunet_comm_open(const void* handle64, void** mapped) {
+    if (!handle64 || !mapped) return YUNET_EINVAL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    return st(hipIpcOpenMemHandle(mapped, h, hipIpcMemLazyEnablePeerAccess));
+}
+
+extern "C" int yunet_comm_close(void* mapped) { return mapped ? st(hipIpcCloseMemHandle(mapped)) : YUNET_EINVAL; }
+
+extern "C" int yunet_allreduce(YunetComm* c, float* buf, size_t n, int mean, void* stream) {
+    if (!c || !buf || c->world < 1 || c->world > YUNET_MAX_RANKS || c->rank < 0 || c->rank >= c->world) return YUNET_EINVAL;
+    if (n == 0) return 0;
+    if (n * 4 > c->slot_bytes || (c->slot_bytes & 15)) return YUNET_EINVAL;
+    ARArgs a;
+    for (int r = 0; r < YUNET_MAX_RANKS; ++r) a.inbox[r] = r < c->world ? static_cast<unsigned char*>(c->inbox[r]) : nullptr;
+    for (int r = 0; r < c->world; ++r)
+        if (!a.inbox[r]) return YUNET_EINVAL;
+    a.status = c->status;
+    a.buf = buf;
+    a.n = n;
+    a.slot_bytes = c->slot_bytes;
+    a.seq = ++c->seq;            // 1, 2, ...: the same on every rank as long as the ranks make the same calls
+    a.rank = c->rank;
+    a.world = c->world;
+    a.scale = mean ? 1.0f / (float)c->world : 1.0f;
+    hipLaunchKernelGGL(oneshot_allreduce_kernel, dim3(c->world), dim3(AR_THREADS), 0, (hipStream_t)stream, a);
+    return -(int)hipGetLastError();
+}
+
+extern "C" int yunet_comm_status(const YunetComm* c) {
+    if (!c || !c->status) return YUNET_EINVAL;
+    return *reinterpret_cast<volatile const int32_t*>(c->status);       // 0, or the sequence number of the call that timed out
+}

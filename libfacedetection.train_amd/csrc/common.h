@@ -227,7 +227,8 @@ struct YunetOptions {
     int bwd64_nw;            // 0 = by shape, 4 | 8: waves per workgroup of dp_bwd64
     int ew_grid;             // workgroup cap of the element-wise backward kernels (default 768)
     int fwd_blocks_per_cu;   // 0 = occupancy API, 1..4: resident workgroups per CU of dp_fwd
-    int fwd64s;              // 1: the plain 64 -> 64 forward unit on the wave-streaming kernel (conv_fwd64.hip)
+    int fwd64s;              // >= 1: the plain 64 -> 64 forward unit on the wave-streaming kernel (conv_fwd64.hip);
+                             // 2 (default): also on the 20 x 20 / 10 x 10 levels instead of the packed tile kernel
     int fwd64s_rows;         // 0 = by shape, else rows per band of that kernel
 };
 YunetOptions& yunet_options();

@@ -769,7 +769,10 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     if (d->cin == ci && d->cout == co) return launch_dp_fwd<ci, co, 8, 16>(d, s);
     if (d->cin == 16 && d->cout == 16 && d->W >= 64 && d->H >= 32)
         return launch_dp_fwd<16, 16, 16, 32>(d, s);   // 160x160 / 80x80 levels: bigger tile
-    if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout))                 // 20x20 / 10x10 levels: packed canvas
+    // 20x20 / 10x10 levels: packed canvas -- except the fp32 64 -> 64 units, which run on the wave-streaming kernel
+    // (one or two 14-column strips per image; option fwd64s = 1 puts them back here: 20 x 20 0.0324 -> 0.0266 ms,
+    // 10 x 10 0.0152 -> 0.0132 ms, profiles/r04_fwd_small.log)
+    if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout) && !(YUNET_ACT_DTYPE == YUNET_F32 && d->cout == 64 && yunet_options().fwd64s >= 2))
         return d->cout == 64 ? launch_dp_fwd<64, 64, 8, 16, true>(d, s) : launch_dp_fwd<64, 16, 8, 16, true>(d, s);
 #ifndef YUNET_ACT_BF16
     // the plain 64 -> 64 unit: wave-streaming kernel (conv_fwd64.hip); the phase-clock debug mode stays on the

@@ -733,6 +733,9 @@ class YuNetEngine:
         self.precision = 'fp32'         # 'fp32' | 'bf16' (activation storage + forward matrix instruction)
         self.lib = L.load()
         self._host_idx = {}
+        # one-shot all-reduce over peer-mapped inboxes (oneshot.py / csrc/collective.hip) instead of the process
+        # group's collectives: one communicator per stream that carries messages
+        self._os_side = self._os_main = None
 
     # ------------------------------------------------------------------ GT staging
     def stage_gt(self, plan, gt_bboxes, gt_keypointss):
@@ -865,11 +868,11 @@ class YuNetEngine:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ea = self._comm_mark(side)
-            self._allreduce_mean(gb[cut:])
+            self._allreduce_mean(gb[cut:], self._os_side)
             self._comm_mark(side, ('bucket_a', ea))
         self._exec(plan.c_bwd_b, 'yunet_exec(bwd_b)')
         eb = self._comm_mark(main)
-        self._allreduce_mean(gb[:cut])
+        self._allreduce_mean(gb[:cut], self._os_main)
         ew = self._comm_mark(main, ('bucket_b', eb))
         main.wait_stream(side)
         self._comm_mark(main, ('wait_a', ew))
@@ -903,9 +906,38 @@ class YuNetEngine:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
-    def _allreduce_mean(self, t):
+    def enable_oneshot(self, verify=True):
+        """Route the step's three messages (num_pos | gradient bucket A on the side stream | bucket B + logged
+        scalars) through the one-shot all-reduce: every rank stores its message into every peer's inbox over xGMI
+        and sums the slots in rank order (csrc/collective.hip).  With `verify`, each communicator first reproduces
+        an all-gather of the process group bit for bit; on a mismatch nothing changes and False is returned."""
+        from .oneshot import OneShotAllReduce
+        nbytes = self.params.grad_buf.numel() * 4
+        comms = [OneShotAllReduce(self.device, nbytes, self.process_group) for _ in range(2)]
+        if verify and not all(c.verify() for c in comms):
+            for c in comms:
+                c.close()
+            return False
+        self._os_side, self._os_main = comms
+        return True
+
+    def disable_oneshot(self):
+        for c in (self._os_side, self._os_main):
+            if c is not None:
+                c.close()
+        self._os_side = self._os_main = None
+
+    def oneshot_status(self):
+        """0, or the sequence number of the first message whose wait for a peer timed out (host read)."""
+        return max((c.status() for c in (self._os_side, self._os_main) if c is not None), default=0)
+
+    def _allreduce_mean(self, t, comm=None):
         """Mean over ranks, in place, on the current stream.  RCCL averages inside the collective
-        (ncclAvg); other backends (gloo: CPU tests, several ranks sharing one GPU) sum, then scale."""
+        (ncclAvg); other backends (gloo: CPU tests, several ranks sharing one GPU) sum, then scale.
+        `comm`: the one-shot communicator of the current stream, when enabled."""
+        if comm is not None:
+            comm.all_reduce_(t, mean=True)
+            return
         pg = self.process_group
         if torch.distributed.get_backend(pg) == 'nccl':
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.AVG, group=pg)
@@ -919,7 +951,10 @@ class YuNetEngine:
         stream, beside the loss kernel (forward())."""
         if self.world_size > 1 or (self.always_bucket and torch.distributed.is_initialized()):
             e0 = self._comm_mark(stream)
-            torch.distributed.all_reduce(norm[0:1], group=self.process_group)
+            if self._os_side is not None:
+                self._os_side.all_reduce_(norm[0:1], stream=stream)
+            else:
+                torch.distributed.all_reduce(norm[0:1], group=self.process_group)
             self._comm_mark(stream, ('num_pos', e0))
 
     def allreduce_grads(self):
@@ -928,7 +963,7 @@ class YuNetEngine:
         in two buckets."""
         if self.world_size <= 1:
             return
-        self._allreduce_mean(self.params.grad_buf)
+        self._allreduce_mean(self.params.grad_buf, self._os_main)
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()

@@ -6,6 +6,8 @@ on first use on a GPU every parameter / buffer is re-pointed to a view of the en
 buffers, so checkpoints load with `strict=True`, `model.parameters()` works with any
 optimizer, and the kernels see one contiguous 303 KB (n) / 218 KB (s) block.
 """
+import os
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -261,6 +263,16 @@ class YuNet(nn.Module):
         if self.engine is not None:
             self.engine.world_size, self.engine.process_group = world_size, group
             self.engine.plans.clear()
+            self.engine.disable_oneshot()
+            self._maybe_oneshot()
+
+    def _maybe_oneshot(self):
+        """YUNET_ONESHOT_AR=1: the step's collectives through peer-mapped inboxes (oneshot.py) instead of the process
+        group; kept only if it reproduces the group's all-gather bit for bit."""
+        if self._world > 1 and os.environ.get('YUNET_ONESHOT_AR') == '1' and self.engine is not None:
+            if not self.engine.enable_oneshot(verify=True):
+                warnings.warn('YUNET_ONESHOT_AR=1: the one-shot all-reduce failed its self-check; '
+                              'staying on the process group collectives')
 
     def _bound(self):
         if self.engine is None:
@@ -285,6 +297,7 @@ class YuNet(nn.Module):
             mod._buffers['running_var'] = fp.running_var[o:o + c]
             mod._buffers['num_batches_tracked'] = fp.num_batches_tracked[i]
         self.engine = eng
+        self._maybe_oneshot()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._log_host = torch.zeros(256, 8, dtype=torch.float32).pin_memory()
         self._log_iter = 0

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/yunet_hip.h but not exported'
     assert sorted(L.EXPORTED) == names, 'ctypes signature table and header disagree'
-    assert lib.yunet_abi_version() == 6
+    assert lib.yunet_abi_version() == 7
     assert lib.yunet_conv_blocks() >= 256
     assert lib.yunet_loss_blocks(256, 2100) >= 1
 
@@ -42,14 +42,15 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     import yunet_amd._lib as L
     src = tmp_path / 'sz.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yunet_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(YunetOp),sizeof(YunetDP),sizeof(YunetBN),sizeof(YunetLevels),'
                    'sizeof(YunetLossCfg),offsetof(YunetOp,p),offsetof(YunetOp,bn),'
-                   'offsetof(YunetOp,dp),offsetof(YunetOp,lv),offsetof(YunetDP,prof));return 0;}')
+                   'offsetof(YunetOp,dp),offsetof(YunetOp,lv),offsetof(YunetDP,prof),sizeof(YunetComm),'
+                   'offsetof(YunetComm,status));return 0;}')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(L.YunetOp), C.sizeof(L.YunetDP), C.sizeof(L.YunetBN), C.sizeof(L.YunetLevels),
             C.sizeof(L.YunetLossCfg), L.YunetOp.p.offset, L.YunetOp.bn.offset, L.YunetOp.dp.offset,
-            L.YunetOp.lv.offset, L.YunetDP.prof.offset]
+            L.YunetOp.lv.offset, L.YunetDP.prof.offset, C.sizeof(L.YunetComm), L.YunetComm.status.offset]
     assert got == want
