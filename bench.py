@@ -264,6 +264,11 @@ def op_name(op, L):
                 forced = OPTS.get('bwd64_nw')
                 nw = forced if forced in (4, 8) else (4 if (not packed and d.W % 16 != 0 and d.W % 8 == 0) else 8)
                 return f"dp_bwd64_kernel<{nw},{'true' if packed else 'false'},{'true' if d.pool_idx else 'false'}>"
+            # round 4: the fp32 16 -> 16 unit on the big maps runs on the wave-streaming kernel that recomputes z
+            # (csrc/conv_bwd16.hip) unless YUNET_BWD16S=0
+            if (big and d.x_dtype == L.F32 and d.out_has_bn and d.dx and not d.accumulate_dx
+                    and int(os.environ.get('YUNET_BWD16S', '1'))):
+                return f"dp_bwd16s_kernel<{'true' if d.pool_idx else 'false'}>"
             gemm = ',0'
             gemm += ',true' if d.pool_idx else ',false'
             # last argument: the whole-tile instance (map = exact multiple of the tile, no validity tests)

@@ -94,6 +94,8 @@ YunetOptions& yunet_options() {
         v.fwd_blocks_per_cu = env("YUNET_DP_FWD_BLOCKS_PER_CU", 0);
         v.fwd64s = env("YUNET_FWD64S", 2);
         v.fwd64s_rows = env("YUNET_FWD64S_ROWS", 0);
+        v.bwd16s = env("YUNET_BWD16S", 1);
+        v.bwd16s_rows = env("YUNET_BWD16S_ROWS", 0);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
         return v;
@@ -111,6 +113,8 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "fwd_blocks_per_cu")) slot = &o.fwd_blocks_per_cu;
     else if (!strcmp(name, "fwd64s")) slot = &o.fwd64s;
     else if (!strcmp(name, "fwd64s_rows")) slot = &o.fwd64s_rows;
+    else if (!strcmp(name, "bwd16s")) slot = &o.bwd16s;
+    else if (!strcmp(name, "bwd16s_rows")) slot = &o.bwd16s_rows;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;
     if (slot == &o.ew_grid && value == 0) value = 768;

@@ -230,6 +230,9 @@ struct YunetOptions {
     int fwd64s;              // >= 1: the plain 64 -> 64 forward unit on the wave-streaming kernel (conv_fwd64.hip);
                              // 2 (default): also on the 20 x 20 / 10 x 10 levels instead of the packed tile kernel
     int fwd64s_rows;         // 0 = by shape, else rows per band of that kernel
+    int bwd16s;              // 1 (default): the fp32 16 -> 16 backward unit on big maps on the wave-streaming kernel that
+                             // recomputes z (conv_bwd16.hip); 0: the tile kernel
+    int bwd16s_rows;         // 0 = by shape, else rows per band of that kernel
 };
 YunetOptions& yunet_options();
 
@@ -293,3 +296,5 @@ static inline int hip_status() { return -(int)hipGetLastError(); }
 
 // conv_fwd64.hip: the plain fp32 64 -> 64 forward unit (no packing, no fused pooling)
 int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream);
+// conv_bwd16.hip: backward of the fp32 16 -> 16 unit (plain or pooled dy), z recomputed from x
+int launch_dp_bwd16s(const YunetDP* d, hipStream_t stream);

@@ -62,6 +62,7 @@ static T* dev(const std::vector<T>& v) {
 static double rel(const std::vector<double>& a, const std::vector<double>& b, size_t lo, size_t hi) {
     double md = 0, mr = 0;
     for (size_t i = lo; i < hi; ++i) {
+        if (a[i] != a[i]) return INFINITY;           // a NaN (e.g. an element the kernel never wrote) must not vanish in fmax
         md = fmax(md, fabs(a[i] - b[i]));
         mr = fmax(mr, fabs(b[i]));
     }
@@ -165,6 +166,50 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dbsi, 2 * ci * 8 * slots));
         const int width = co * ci + co + co * 9 + co;
         std::vector<double> ref_dx, ref_w, ref_b;
+        if (getenv("ZFWD") && !getenv("FWD")) {
+            // ZFWD=1: z = the unit's FORWARD output for x and the weights (first variant's forward kernel) instead of
+            // independent noise -- what backward kernels that recompute z from x need; the output BN's forward and
+            // backward sums are re-derived from it
+            double* dtmp;
+            CK(hipMalloc(&dtmp, 2 * co * 8 * slots));
+            CK(hipMemset(dtmp, 0, 2 * co * 8 * slots));
+            YunetDP f;
+            memset(&f, 0, sizeof(f));
+            f.N = N; f.H = H; f.W = W; f.cin = ci; f.cout = co;
+            f.in_transform = YUNET_T_BNRELU; f.out_has_bn = 1;
+            f.x_img_stride = (int64_t)H * W * ci; f.z_img_stride = (int64_t)H * W * co;
+            f.x = dx_x;
+            f.in_bn = YunetBN{dsin, nullptr, dgi, dbi, (int32_t)px, 1e-5f, slots};
+            f.w_pw = dwp; f.b_pw = dbp; f.w_dw = dwd; f.b_dw = dbd;
+            f.z = dz;
+            f.out_bn = YunetBN{dtmp, nullptr, dgo, dbo, (int32_t)px, 1e-5f, slots};
+            // (inside the first variant's environment: a library reads its switches on first use)
+            if (!vs[0].env_k.empty()) setenv(vs[0].env_k.c_str(), vs[0].env_v.c_str(), 1);
+            const int rcf = vs[0].fwd(&f, st);
+            CK(hipStreamSynchronize(st));
+            if (!vs[0].env_k.empty()) unsetenv(vs[0].env_k.c_str());
+            if (rcf != 0) { printf("ZFWD: forward rc=%d\n", rcf); exit(2); }
+            CK(hipMemcpy(z.data(), dz, z.size() * 4, hipMemcpyDeviceToHost));
+            std::fill(sout.begin(), sout.end(), 0.0);
+            for (size_t p = 0; p < px; ++p)
+                for (int c = 0; c < co; ++c) {
+                    const double v = z[p * co + c];
+                    sout[c] += v; sout[co + c] += v * v;
+                }
+            for (int c = 0; c < co; ++c) {
+                const double mean = sout[c] / px, var = sout[co + c] / px - mean * mean, inv = 1.0 / sqrt(var + 1e-5);
+                double s0 = 0, s1 = 0;
+                for (size_t p = 0; p < px; ++p) {
+                    const double g = dy[p * co + c];
+                    s0 += g; s1 += g * (z[p * co + c] - mean) * inv;
+                }
+                bso[c] = s0; bso[co + c] = s1;
+            }
+            const std::vector<double> ps = padded(sout), pb = padded(bso);
+            CK(hipMemcpy(dsout, ps.data(), ps.size() * 8, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dbso, pb.data(), pb.size() * 8, hipMemcpyHostToDevice));
+            hipFree(dtmp);
+        }
         if (getenv("FWD")) {
             // FWD=1: the FORWARD kernel instead (z and the output BN sums against the first variant)
             float* dzo;
@@ -274,6 +319,7 @@ int main(int argc, char** argv) {
                     d.prof = (unsigned long long*)((uintptr_t)dprof | ((uintptr_t)atoll(getenv("ABL")) & 63));
             }
             CK(hipMemsetAsync(dbsi, 0, 2 * ci * 8 * slots, st));
+            CK(hipMemsetAsync(ddx, 0xff, px * ci * 4, st));       // NaN: a variant that skips a dx element must not inherit the previous one's
             int rc = v.bwd(&d, st);
             CK(hipStreamSynchronize(st));
             if (rc != 0) {
