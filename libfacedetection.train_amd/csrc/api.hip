@@ -138,20 +138,29 @@ int yunet_upadd_bwd_bf16(const float*, const YunetBN*, const float*, const Yunet
 
 // Op lists select the activation storage type per op: YunetDP.x_dtype for the ConvDPUnits, i[11] for
 // the stem / pool / upsample-add ops (0 = fp32, 1 = bf16).
-// ---- lanes: side streams + events of the executor (one set per process; created on first use) -------------------
+// ---- lanes: side streams + events of the executor, one set per (host thread, device), created on first use: two
+// threads (or two devices) replaying op lists never share an event, and a side stream always belongs to the device
+// that is current in the calling thread
 static int g_lanes_on = 1;
-static hipStream_t g_side[YUNET_MAX_LANES];
-static hipEvent_t g_fork_ev, g_join_ev[YUNET_MAX_LANES];
-static bool g_lanes_ready = false;
-static int lanes_init() {
-    if (g_lanes_ready) return 0;
+struct LaneSet {
+    bool ready;
+    hipStream_t side[YUNET_MAX_LANES];
+    hipEvent_t fork_ev, join_ev[YUNET_MAX_LANES];
+};
+static constexpr int kMaxDevices = 16;
+static thread_local LaneSet t_lanes[kMaxDevices];
+static LaneSet* lanes_get() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    LaneSet& s = t_lanes[dev];
+    if (s.ready) return &s;
     for (int l = 0; l < YUNET_MAX_LANES; ++l) {
-        if (hipStreamCreateWithFlags(&g_side[l], hipStreamNonBlocking) != hipSuccess) return YUNET_EINVAL;
-        if (hipEventCreateWithFlags(&g_join_ev[l], hipEventDisableTiming) != hipSuccess) return YUNET_EINVAL;
+        if (hipStreamCreateWithFlags(&s.side[l], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&s.join_ev[l], hipEventDisableTiming) != hipSuccess) return nullptr;
     }
-    if (hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming) != hipSuccess) return YUNET_EINVAL;
-    g_lanes_ready = true;
-    return 0;
+    if (hipEventCreateWithFlags(&s.fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.ready = true;
+    return &s;
 }
 extern "C" int yunet_exec_lanes(int enable) {
     const int prev = g_lanes_on;
@@ -161,24 +170,25 @@ extern "C" int yunet_exec_lanes(int enable) {
 
 extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
     unsigned open_lanes = 0;
+    LaneSet* ls = nullptr;
     for (int k = 0; k < n_ops; ++k) {
         const YunetOp& o = ops[k];
         int rc = 0;
         void* stream = main_stream;
         if (o.opcode == YUNET_OP_FORK || o.opcode == YUNET_OP_JOIN) {
             if (!g_lanes_on) continue;
-            if (lanes_init() != 0) return YUNET_EINVAL * 1000 - k;
+            if (!ls && !(ls = lanes_get())) return YUNET_EINVAL * 1000 - k;
             const unsigned mask = (unsigned)o.i[0] & ((1u << (YUNET_MAX_LANES + 1)) - 2u);
             if (o.opcode == YUNET_OP_FORK) {
-                if (hipEventRecord(g_fork_ev, (hipStream_t)main_stream) != hipSuccess) return YUNET_EINVAL * 1000 - k;
+                if (hipEventRecord(ls->fork_ev, (hipStream_t)main_stream) != hipSuccess) return YUNET_EINVAL * 1000 - k;
                 for (int l = 1; l <= YUNET_MAX_LANES; ++l)
-                    if (mask & (1u << l)) hipStreamWaitEvent(g_side[l - 1], g_fork_ev, 0);
+                    if (mask & (1u << l)) hipStreamWaitEvent(ls->side[l - 1], ls->fork_ev, 0);
                 open_lanes |= mask;
             } else {
                 for (int l = 1; l <= YUNET_MAX_LANES; ++l)
                     if (mask & (1u << l)) {
-                        hipEventRecord(g_join_ev[l - 1], g_side[l - 1]);
-                        hipStreamWaitEvent((hipStream_t)main_stream, g_join_ev[l - 1], 0);
+                        hipEventRecord(ls->join_ev[l - 1], ls->side[l - 1]);
+                        hipStreamWaitEvent((hipStream_t)main_stream, ls->join_ev[l - 1], 0);
                     }
                 open_lanes &= ~mask;
             }
@@ -186,8 +196,8 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
         }
         const int lane = o.i[YUNET_OP_LANE];
         if (g_lanes_on && lane > 0) {
-            if (lane > YUNET_MAX_LANES || !(open_lanes & (1u << lane))) return YUNET_EINVAL * 1000 - k;   // not forked
-            stream = (void*)g_side[lane - 1];
+            if (lane > YUNET_MAX_LANES || !(open_lanes & (1u << lane)) || !ls) return YUNET_EINVAL * 1000 - k;   // not forked
+            stream = (void*)ls->side[lane - 1];
         }
         switch (o.opcode) {
             case YUNET_OP_STEM_FWD:
@@ -283,8 +293,8 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
     if (open_lanes) {      // a list must not end with work pending on a side stream: join defensively, report
         for (int l = 1; l <= YUNET_MAX_LANES; ++l)
             if (open_lanes & (1u << l)) {
-                hipEventRecord(g_join_ev[l - 1], g_side[l - 1]);
-                hipStreamWaitEvent((hipStream_t)main_stream, g_join_ev[l - 1], 0);
+                hipEventRecord(ls->join_ev[l - 1], ls->side[l - 1]);
+                hipStreamWaitEvent((hipStream_t)main_stream, ls->join_ev[l - 1], 0);
             }
         return YUNET_EINVAL * 1000 - n_ops;
     }

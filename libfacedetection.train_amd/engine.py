@@ -790,6 +790,9 @@ class YuNetEngine:
             # --mode 2) walks through hundreds: keep the most recently used ones, drop the rest (a dropped plan
             # stays alive while an autograd graph or `eng.plan` still refers to it)
             while len(self.plans) > MAX_PLANS:
+                # a dropped plan returns its buffers to the caching allocator; work issued on the comm side stream
+                # (or on executor lanes) does not hold them alive: drain the device first (rare: > 16 shapes walked)
+                torch.cuda.synchronize(self.device)
                 self.plans.popitem(last=False)
         else:
             self.plans.move_to_end(key)

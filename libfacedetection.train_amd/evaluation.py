@@ -318,3 +318,33 @@ def single_gpu_test(model, dataset, device, scale=(640, 640), max_images=None):
     if was_training:
         model.train()
     return out
+
+
+def multi_gpu_test(model, dataset, device, scale=(640, 640), max_images=None, group=None):
+    """mmdet/apis/test.py multi_gpu_test for this path (what the reference's DistEvalHook runs): rank r takes the
+    images r, r + world, r + 2 world, ...; the per-image results are gathered and put back in dataset order
+    (collect_results).  Returns the full list on rank 0 and None on the other ranks."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    was_training = model.training
+    model.eval()
+    n = len(dataset) if max_images is None else min(len(dataset), max_images)
+    part = []
+    with torch.no_grad():
+        for i in range(rank, n, world):
+            img, meta = prepare_test_image(dataset.load_image(i), scale, device)
+            meta['ori_filename'] = dataset.data_infos[i]['filename']
+            part.append(model(return_loss=False, rescale=True, img=[img], img_metas=[[meta]])[0])
+    if was_training:
+        model.train()
+    parts = [None] * world
+    dist.all_gather_object(parts, part, group=group)
+    if rank != 0:
+        return None
+    out = [None] * n
+    for r, p in enumerate(parts):
+        for k, res in enumerate(p):
+            out[r + k * world] = res
+    return out
+

@@ -7,6 +7,7 @@ Per iteration, exactly the reference's order: lr hook -> model.train_step(batch,
 """
 import os
 import time
+import warnings
 
 import torch
 
@@ -246,18 +247,23 @@ class CheckpointHook(Hook):
 
 
 class EvalHook(Hook):
-    """mmdet/core/evaluation/eval_hooks.py:24-66 on this path: every `interval` epochs (by_epoch) or iterations,
-    rank 0 runs the detector in eval mode over the validation set (evaluation.single_gpu_test: the device test
-    pipeline + get_bboxes), calls dataset.evaluate(results, metric=...) and files the numbers in the log
-    (runner.log_buffer entries tagged mode='val').  The shipped configs set interval=1001 (> max_epochs): the hook
-    is registered, as in the reference, and never fires there.  DistEvalHook: the other ranks wait at a barrier
-    (the validation set is small next to an epoch; the reference shards it over ranks)."""
+    """mmdet/core/evaluation/eval_hooks.py:24-66 on this path: every `interval` epochs (by_epoch) or iterations the
+    detector runs in eval mode over the validation set (the device test pipeline + get_bboxes), rank 0 calls
+    dataset.evaluate(results, metric=...) and files the numbers in the log (runner.log_buffer entries tagged
+    mode='val').  The shipped configs set interval=1001 (> max_epochs): the hook is registered, as in the reference,
+    and never fires there.  Distributed (DistEvalHook): the images are sharded over the ranks and the results gathered
+    on rank 0 (evaluation.multi_gpu_test), as the reference does -- no rank idles behind a barrier."""
 
     def __init__(self, dataset, interval=1, by_epoch=True, metric='mAP', start=None, scale=(640, 640),
                  max_images=None, save_best=None, distributed=False, **eval_kwargs):
         self.dataset, self.interval, self.by_epoch, self.metric = dataset, int(interval), by_epoch, metric
         self.start, self.scale, self.max_images, self.distributed = start, scale, max_images, distributed
         self.eval_kwargs = {k: v for k, v in eval_kwargs.items() if k in ('iou_thr',)}
+        dropped = sorted(k for k in eval_kwargs if k not in self.eval_kwargs)
+        if save_best is not None:
+            dropped.append('save_best')
+        if dropped:      # (mmcv's EvalHook options this path does not implement: say so instead of dropping them silently)
+            warnings.warn(f'EvalHook: evaluation options {dropped} are not supported on this path and are ignored')
         self.best, self.results = None, []
 
     def _should(self, runner, count):
@@ -274,13 +280,17 @@ class EvalHook(Hook):
             self._evaluate(runner)
 
     def _evaluate(self, runner):
-        from .evaluation import single_gpu_test
-        if runner.rank == 0:
-            target = runner.model.module if hasattr(runner.model, 'module') else runner.model
-            dev = torch.device(runner.device) if not isinstance(runner.device, torch.device) else runner.device
-            if dev.type == 'cuda' and dev.index is None:
-                dev = torch.device('cuda', torch.cuda.current_device())
-            dets = single_gpu_test(target, self.dataset, dev, self.scale, self.max_images)
+        from .evaluation import multi_gpu_test, single_gpu_test
+        target = runner.model.module if hasattr(runner.model, 'module') else runner.model
+        dev = torch.device(runner.device) if not isinstance(runner.device, torch.device) else runner.device
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        sharded = self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if sharded:
+            dets = multi_gpu_test(target, self.dataset, dev, self.scale, self.max_images)      # None off rank 0
+        else:
+            dets = single_gpu_test(target, self.dataset, dev, self.scale, self.max_images) if runner.rank == 0 else None
+        if dets is not None:
             res = self.dataset.evaluate(dets, metric=self.metric, **self.eval_kwargs)
             done = runner.iter if self.by_epoch else runner.iter + 1          # iterations completed so far
             entry = dict(mode='val', epoch=runner.epoch + 1, iter=done, **{k: float(v) for k, v in res.items()})
@@ -290,8 +300,6 @@ class EvalHook(Hook):
                                                        ', '.join(f'{k}: {float(v):.4f}' for k, v in res.items())))
             if self.best is None or res.get('mAP', 0.0) > self.best:
                 self.best = res.get('mAP', 0.0)
-        if self.distributed and torch.distributed.is_initialized():
-            torch.distributed.barrier()
 
 
 class LoggerHook(Hook):

@@ -107,3 +107,46 @@ def test_ddp_scatter_keeps_padded_gt_lists():
     gk.padded, gk.counts = torch.zeros(3, 64, 5, 3), cnt
     gb2, _, c2 = pad_gt(got, gk, 'cpu')
     assert c2.tolist() == cnt.tolist() and gb2.shape[1] == 5
+
+
+class _FakeSet:
+    """7 images whose pixel (0, 0) carries the image index."""
+    def __init__(self, n=7):
+        import numpy as np
+        self.data_infos = [dict(filename=f'ev/img_{i}.jpg') for i in range(n)]
+        self._np = np
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def load_image(self, i):
+        img = self._np.zeros((40, 56, 3), dtype=self._np.uint8)
+        img[0, 0, 0] = i
+        return img
+
+
+class _FakeDetector(torch.nn.Module):
+    def forward(self, return_loss=False, rescale=True, img=None, img_metas=None):
+        import numpy as np
+        i = int(img[0][0, 0, 0, 0])
+        return [[np.array([[i, i, i + 1, i + 1, 0.5]], dtype=np.float32)]]
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from yunet_amd.evaluation import multi_gpu_test
+    res = multi_gpu_test(_FakeDetector(), _FakeSet(), 'cpu', scale=None)
+    out[rank] = None if res is None else [float(r[0][0, 0]) for r in res]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_restores_dataset_order():
+    """DistEvalHook's multi_gpu_test (mmdet/apis/test.py): images interleaved over the ranks, results gathered on
+    rank 0 in dataset order."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0] and out[1] is None

@@ -69,7 +69,9 @@ SHAPES = [(2, 10, 10), (3, 20, 40), (1, 24, 16), (2, 5, 5),
 #   (70, 20, 20): packed canvas with 5 canvas rows -> 30 x 10 = 300 packed tiles > 256 workgroups;
 #   (40, 40, 40): width a multiple of 8 but not of 16 -> dp_bwd64 on 8 x 8 tiles with 4 waves, two workgroups per
 #   CU (round 3): 1000 tiles > the 512-workgroup grid, the one-float-per-thread remainder of its halo.
-BIG_SHAPES = {(16, 16): [(2, 64, 96), (1, 160, 160), (9, 96, 128)],
+#   (3, 40, 72), (5, 50, 70): big-tile class with ragged strips / bands of the wave-streaming 16 -> 16 backward
+#   (conv_bwd16.hip: 28-column strips -> 28 + 28 + 16 and 28 + 28 + 14 columns; band heights that do not divide H)
+BIG_SHAPES = {(16, 16): [(2, 64, 96), (1, 160, 160), (9, 96, 128), (3, 40, 72), (5, 50, 70)],
               (64, 64): [(40, 80, 80), (70, 20, 20), (40, 40, 40)],
               (16, 64): [(40, 80, 80)],
               (64, 16): [(40, 80, 80), (70, 20, 20)]}
