@@ -792,7 +792,8 @@ class YuNetEngine:
             while len(self.plans) > MAX_PLANS:
                 # a dropped plan returns its buffers to the caching allocator; work issued on the comm side stream
                 # (or on executor lanes) does not hold them alive: drain the device first (rare: > 16 shapes walked)
-                torch.cuda.synchronize(self.device)
+                if self.device.type == 'cuda' and torch.cuda.is_available():
+                    torch.cuda.synchronize(self.device)
                 self.plans.popitem(last=False)
         else:
             self.plans.move_to_end(key)

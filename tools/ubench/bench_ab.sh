@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out; mkdir -p $OUT
 L=$OUT/${TAG:-r04_bench_ab}.log; : > $L
+SHOW=${SHOW:-"bwd16s stem"}
 for rep in 1 2; do
 for cfg in "$@"; do
   echo "== [$rep] $cfg" >> $L
@@ -12,7 +13,7 @@ b=json.loads(sys.stdin.read())
 print(b['ms_per_step'], b['value'])
 ks=b.get('kernels',{})
 for k,v in ks.items():
-    if '16,16' in k or 'bwd16s' in k or 'fwd64s' in k or '64,64,8,16,true' in k: print('   ',k,v)
+    if any(w in k for w in '''$SHOW'''.split()): print('   ',k,v)
 " >> $L 2>&1
 done
 done
