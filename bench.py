@@ -246,6 +246,9 @@ def op_name(op, L):
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
              L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',
              L.OP_REDUCE_BATCH: 'reduce_partials_batch_kernel', L.OP_BN_BATCH: 'bn_batch_kernel'}
+    if op.opcode in (L.OP_STEM_FWD, L.OP_STEM_BWD) and op.i[11] != L.BF16 and int(os.environ.get('YUNET_STEM_MMA', '1')):
+        # round 4: the fp32 stem as matrix products (csrc/conv_stem.hip); the backward recomputes z from the image
+        return 'stem_mma_kernel<false>' if op.opcode == L.OP_STEM_FWD else 'stem_mma_kernel<true>'
     if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
         # the template instance the C dispatcher picks (csrc/conv_fwd.hip / conv_bwd.hip / common.h):
         # 16x32 tiles for 16->16 on big maps, packed-canvas tiling for 64->{64,16} on maps <= 20x20

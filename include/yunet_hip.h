@@ -118,6 +118,11 @@ int yunet_stem_bwd(const float* img, const float* z, const float* dy, const Yune
                    float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
                    void* stream);
 
+/* The same weight gradient with z RECOMPUTED from the image (w [cmid,3,3,3], b [cmid]: the stem's parameters) instead of
+ * read -- 112 instead of 176 bytes per output pixel -- as two matrix products on the matrix cores.  fp32 storage only. */
+int yunet_stem_bwd_rz(const float* img, const float* w, const float* b, const float* dy, const YunetBN* bn,
+                      float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid, void* stream);
+
 int yunet_dp_fwd(const YunetDP* d, void* stream);
 int yunet_dp_bwd(const YunetDP* d, void* stream);
 /* rows of wgrad_partials (= persistent grid) yunet_dp_bwd / yunet_stem_bwd use for a shape */
@@ -401,6 +406,10 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "fwd64s"             0: every fp32 64 -> 64 forward unit on the tile kernel | 1: the plain and fused-pooling units on
  *                        the wave-streaming kernel | 2 (default): the 20x20 / 10x10 levels too
  *   "fwd64s_rows"        0 (by shape) | rows per band of the wave-streaming kernel
+ *   "bwd16s"             1 (default): the fp32 16 -> 16 backward unit on maps >= 32 x 64 on the wave-streaming kernel that
+ *                        recomputes z (it does not read YunetDP.z) | 0: the tile kernel;  "bwd16s_rows": rows per band
+ *   "stem_mma"           1 (default): the fp32 stem (yunet_stem_fwd; YUNET_OP_STEM_BWD with the stem's parameters in p[4],
+ *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
 int yunet_set_option(const char* name, int value);

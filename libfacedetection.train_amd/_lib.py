@@ -84,6 +84,7 @@ _SIGNATURES = {
     'yunet_stem_fwd': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     'yunet_stem_bwd': (C.c_int, [C.c_void_p] * 3 + [C.POINTER(YunetBN), C.c_void_p] +
                        [C.c_int] * 5 + [C.c_void_p]),
+    'yunet_stem_bwd_rz': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     'yunet_dp_fwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
     'yunet_dp_bwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
     'yunet_dp_bwd_blocks': (C.c_int, [C.c_int] * 5),

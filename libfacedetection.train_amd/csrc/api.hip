@@ -96,6 +96,7 @@ YunetOptions& yunet_options() {
         v.fwd64s_rows = env("YUNET_FWD64S_ROWS", 0);
         v.bwd16s = env("YUNET_BWD16S", 1);
         v.bwd16s_rows = env("YUNET_BWD16S_ROWS", 0);
+        v.stem_mma = env("YUNET_STEM_MMA", 1);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
         return v;
@@ -115,6 +116,7 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "fwd64s_rows")) slot = &o.fwd64s_rows;
     else if (!strcmp(name, "bwd16s")) slot = &o.bwd16s;
     else if (!strcmp(name, "bwd16s_rows")) slot = &o.bwd16s_rows;
+    else if (!strcmp(name, "stem_mma")) slot = &o.stem_mma;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;
     if (slot == &o.ew_grid && value == 0) value = 768;
@@ -206,6 +208,12 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
                                     stream);
                 break;
             case YUNET_OP_STEM_BWD:
+                // p[4], p[5] = the stem's weights / bias: with fp32 storage the weight gradient recomputes z from the image
+                if (o.i[11] != YUNET_BF16 && o.p[4] && o.p[5] && yunet_options().stem_mma) {
+                    rc = yunet_stem_bwd_rz((const float*)o.p[0], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[2],
+                                           &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                    break;
+                }
                 rc = (o.i[11] == YUNET_BF16 ? yunet_stem_bwd_bf16 : yunet_stem_bwd)((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                     &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3],
                                     stream);

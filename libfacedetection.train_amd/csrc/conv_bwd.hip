@@ -2246,6 +2246,16 @@ extern "C" int ACT_SUFFIX(yunet_stem_bwd)(const float* img, const float* z, cons
     return hip_status();
 }
 
+#ifndef YUNET_ACT_BF16
+// the same weight gradient on the matrix cores with z RECOMPUTED from the image (w [16,3,3,3], b [16]: the stem's
+// parameters) instead of read: 112 instead of 176 bytes per output pixel (conv_stem.hip)
+extern "C" int yunet_stem_bwd_rz(const float* img, const float* w, const float* b, const float* dy, const YunetBN* bn,
+                                 float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid, void* stream) {
+    if (cmid != 16 || (H & 1) || (W & 1) || !w || !b || !bn->bstats || wgrad_blocks != yunet_stem_bwd_blocks(N, H, W)) return YUNET_EINVAL;
+    return launch_stem_bwd_mma(img, w, b, dy, bn, wgrad_partials, wgrad_blocks, N, H, W, (hipStream_t)stream);
+}
+#endif
+
 extern "C" int ACT_SUFFIX(yunet_pool_bwd)(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
                                           int accumulate, int N, int H, int W, int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;

@@ -740,6 +740,10 @@ inline int ew_grid(long long total) {
 extern "C" int ACT_SUFFIX(yunet_stem_fwd)(const float* img, const float* w, const float* b, float* z,
                                           double* stats, int N, int H, int W, int cmid, void* stream) {
     if (cmid != 16 || (H & 1) || (W & 1)) return YUNET_EINVAL;
+#ifndef YUNET_ACT_BF16
+    // fp32 storage: the convolution as a matrix product on the matrix cores (conv_stem.hip)
+    if (yunet_options().stem_mma) return launch_stem_fwd_mma(img, w, b, z, stats, N, H, W, (hipStream_t)stream);
+#endif
     const int tiles = N * ((W / 2 + STEM_TW - 1) / STEM_TW) * ((H / 2 + STEM_TH - 1) / STEM_TH);
     // persistent grid = resident workgroups (158 VGPRs -> 3 waves/SIMD -> 3 per CU on 256 CUs)
     const int grid = tiles < 768 ? tiles : 768;

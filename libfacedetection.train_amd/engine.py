@@ -561,7 +561,7 @@ class Plan:
         def bwd():
             assert z0.grad is not None
             op = self._op(L.OP_STEM_BWD, p=[None, z0.buf.data_ptr(), z0.grad.data_ptr(),
-                                            part.data_ptr()],
+                                            part.data_ptr(), wp, bp],      # wp, bp: fp32 storage recomputes z from the image
                           i=[self.n, self.h, self.w, 16, blocks])
             op.bn[0] = self._bn_struct('backbone.model0.bn1', cnt)
             self.bwd.append(op)

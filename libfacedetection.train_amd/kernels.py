@@ -87,15 +87,20 @@ def stem_fwd(img, w, b, stats, dtype=torch.float32):
     return z
 
 
-def stem_bwd(img, z, dy, bn):
-    """-> (dw [16,3,3,3], db [16]) given dy = grad wrt bn1 output (ReLU-masked)."""
-    n, _, h, w = img.shape
-    blocks = stem_grid(n, h, w)
+def stem_bwd(img, z, dy, bn, w=None, b=None):
+    """-> (dw [16,3,3,3], db [16]) given dy = grad wrt bn1 output (ReLU-masked).  With the stem's parameters (w, b) and
+    fp32 storage, z is recomputed from the image instead of read (yunet_stem_bwd_rz: what a training step runs)."""
+    n, _, h, wd = img.shape
+    blocks = stem_grid(n, h, wd)
     width = 16 * 27 + 16
     part = torch.empty(blocks, width, device=img.device, dtype=torch.float32)
     bnc = bn.c()
-    fn = getattr(L.load(), 'yunet_stem_bwd' + _act(z)[1])
-    L.check(fn(_p(img), _p(z), _p(dy), C.byref(bnc), _p(part), blocks, n, h, w, 16, _stream()), 'yunet_stem_bwd')
+    if w is not None and b is not None and _act(z)[1] == '':
+        L.check(L.load().yunet_stem_bwd_rz(_p(img), _p(w), _p(b), _p(dy), C.byref(bnc), _p(part), blocks, n, h, wd, 16,
+                                           _stream()), 'yunet_stem_bwd_rz')
+    else:
+        fn = getattr(L.load(), 'yunet_stem_bwd' + _act(z)[1])
+        L.check(fn(_p(img), _p(z), _p(dy), C.byref(bnc), _p(part), blocks, n, h, wd, 16, _stream()), 'yunet_stem_bwd')
     out = torch.empty(width, device=img.device, dtype=torch.float32)
     reduce_partials(part, out)
     return out[:432].view(16, 3, 3, 3), out[432:]

@@ -202,7 +202,7 @@ def test_dp_bwd_accumulate():
     assert torch.allclose(dx1, base + dx0, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize('n,h,w', [(2, 32, 32), (3, 64, 96), (1, 20, 36)])
+@pytest.mark.parametrize('n,h,w', [(2, 32, 32), (3, 64, 96), (1, 20, 36), (2, 320, 320), (5, 66, 150)])
 def test_stem_fwd_bwd(n, h, w):
     k = K()
     g = torch.Generator().manual_seed(h)
@@ -227,6 +227,25 @@ def test_stem_fwd_bwd(n, h, w):
     torch.cuda.synchronize()
     assert rel_err(dw, wt.grad) < 1e-4
     assert float(db.abs().max()) < 1e-3 * float(dy.abs().sum())
+    # the variant a training step runs: both products on the matrix cores, z recomputed from the image (yunet_stem_bwd_rz)
+    dw2, db2 = k.stem_bwd(img.to(DEV), zg, nhwc(dy.float()).to(DEV), bn, wt.detach().float().to(DEV).contiguous(),
+                          b.detach().float().to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(dw2, wt.grad) < 1e-4
+    assert float(db2.abs().max()) < 1e-3 * float(dy.abs().sum())
+    # and the VALU tile kernel behind the option (its aligned 16-byte patch loads want W % 4 == 0; the engine feeds
+    # multiples of 32)
+    if w % 4:
+        return
+    import yunet_amd._lib as L
+    prev = L.set_option('stem_mma', 0)
+    try:
+        stats0 = torch.zeros(32, dtype=torch.float64, device=DEV)
+        zg0 = k.stem_fwd(img.to(DEV), wt.detach().float().to(DEV), b.detach().float().to(DEV), stats0)
+        torch.cuda.synchronize()
+        assert rel_err(nchw(zg0.cpu()), z.detach()) < 2e-5 and rel_err(stats0, stats_of(nhwc(z.detach()))) < 2e-5
+    finally:
+        L.set_option('stem_mma', prev)
 
 
 @pytest.mark.parametrize('c', [16, 32, 64])
