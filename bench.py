@@ -282,6 +282,10 @@ def op_name(op, L):
             gemm += ',true' if full else ',false'
         else:
             # round 4: the plain fp32 64 -> 64 forward unit runs on the wave-streaming kernel (csrc/conv_fwd64.hip)
+            # the fp32 units with 16 input channels (16 -> 16 plain / fused pooling, 16 -> 64): csrc/conv_fwd16.hip
+            if (d.cin == 16 and d.x_dtype == L.F32 and d.z_dtype == L.F32 and int(os.environ.get('YUNET_FWD16S', '1'))
+                    and (d.cout == 16 or (d.cout == 64 and not d.pool_out))):
+                return f"dp_fwd16s_kernel<{d.cout},{'true' if d.pool_out else 'false'}>"
             # (since the small-level measurement also on the 20 x 20 / 10 x 10 levels unless YUNET_FWD64S=1)
             f64s = int(os.environ.get('YUNET_FWD64S', '2'))
             if d.cin == 64 and d.cout == 64 and d.x_dtype == L.F32 and f64s >= (2 if packed else 1):

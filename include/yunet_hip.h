@@ -408,6 +408,7 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "fwd64s_rows"        0 (by shape) | rows per band of the wave-streaming kernel
  *   "bwd16s"             1 (default): the fp32 16 -> 16 backward unit on maps >= 32 x 64 on the wave-streaming kernel that
  *                        recomputes z (it does not read YunetDP.z) | 0: the tile kernel;  "bwd16s_rows": rows per band
+ *   "fwd16s"             1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernels | 0: the tile kernels
  *   "stem_mma"           1 (default): the fp32 stem (yunet_stem_fwd; YUNET_OP_STEM_BWD with the stem's parameters in p[4],
  *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.

@@ -233,6 +233,7 @@ struct YunetOptions {
     int bwd16s;              // 1 (default): the fp32 16 -> 16 backward unit on big maps on the wave-streaming kernel that
                              // recomputes z (conv_bwd16.hip); 0: the tile kernel
     int bwd16s_rows;         // 0 = by shape, else rows per band of that kernel
+    int fwd16s;              // 1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernel (conv_fwd16.hip)
     int stem_mma;            // 1 (default): the fp32 stem forward / weight gradient on the matrix cores (conv_stem.hip; the
                              // backward recomputes z from the image); 0: the VALU tile kernels
 };
@@ -300,6 +301,8 @@ static inline int hip_status() { return -(int)hipGetLastError(); }
 int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream);
 // conv_bwd16.hip: backward of the fp32 16 -> 16 unit (plain or pooled dy), z recomputed from x
 int launch_dp_bwd16s(const YunetDP* d, hipStream_t stream);
+// conv_fwd16.hip: forward of the fp32 16 -> 16 (plain | fused pooling) and 16 -> 64 units
+int launch_dp_fwd16s(const YunetDP* d, hipStream_t stream);
 // conv_stem.hip: the fp32 stem on the matrix cores (forward; weight gradient with z recomputed from the image)
 int launch_stem_fwd_mma(const float* img, const float* w, const float* b, float* z, double* stats, int N, int H, int W,
                         hipStream_t stream);

@@ -757,6 +757,13 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     if (d->z_dtype != YUNET_ACT_DTYPE && !(d->cout == 16 && d->z_dtype == YUNET_F32)) return YUNET_EINVAL;
     if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU) return YUNET_EINVAL;
+#ifndef YUNET_ACT_BF16
+    // fp32 units with 16 input channels: wave-streaming kernels (conv_fwd16.hip)
+    if (d->cin == 16 && (d->cout == 16 || (d->cout == 64 && !d->pool_out)) && d->z_dtype == YUNET_F32 && !d->prof && yunet_options().fwd16s &&
+        (!d->pool_out || (yunet_dp_pool_fusion_ok(d->N, d->H, d->W, 16, 16) && d->out_bn.gamma && d->pool_idx &&
+                          !(reinterpret_cast<uintptr_t>(d->pool_idx) & 3))))
+        return launch_dp_fwd16s(d, s);
+#endif
     if (d->pool_out) {
         // also write the raw max_pool2d winners + their window positions (fused pooling)
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_bn.gamma || !d->pool_idx ||   // (out_has_bn may be 0: eval())
