@@ -246,8 +246,9 @@ def op_name(op, L):
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
              L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',
              L.OP_REDUCE_BATCH: 'reduce_partials_batch_kernel', L.OP_BN_BATCH: 'bn_batch_kernel'}
-    if op.opcode in (L.OP_STEM_FWD, L.OP_STEM_BWD) and op.i[11] != L.BF16 and int(os.environ.get('YUNET_STEM_MMA', '1')):
-        # round 4: the fp32 stem as matrix products (csrc/conv_stem.hip); the backward recomputes z from the image
+    if (op.opcode in (L.OP_STEM_FWD, L.OP_STEM_BWD) and int(os.environ.get('YUNET_STEM_MMA', '1'))
+            and (op.opcode == L.OP_STEM_FWD or op.i[11] != L.BF16)):
+        # round 4: the stem as matrix products (csrc/conv_stem.hip); the fp32-storage backward recomputes z from the image
         return 'stem_mma_kernel<false>' if op.opcode == L.OP_STEM_FWD else 'stem_mma_kernel<true>'
     if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
         # the template instance the C dispatcher picks (csrc/conv_fwd.hip / conv_bwd.hip / common.h):
@@ -283,12 +284,12 @@ def op_name(op, L):
         else:
             # round 4: the plain fp32 64 -> 64 forward unit runs on the wave-streaming kernel (csrc/conv_fwd64.hip)
             # the fp32 units with 16 input channels (16 -> 16 plain / fused pooling, 16 -> 64): csrc/conv_fwd16.hip
-            if (d.cin == 16 and d.x_dtype == L.F32 and d.z_dtype == L.F32 and int(os.environ.get('YUNET_FWD16S', '1'))
+            if (d.cin == 16 and d.z_dtype == d.x_dtype and int(os.environ.get('YUNET_FWD16S', '1'))
                     and (d.cout == 16 or (d.cout == 64 and not d.pool_out))):
                 return f"dp_fwd16s_kernel<{d.cout},{'true' if d.pool_out else 'false'}>"
             # (since the small-level measurement also on the 20 x 20 / 10 x 10 levels unless YUNET_FWD64S=1)
             f64s = int(os.environ.get('YUNET_FWD64S', '2'))
-            if d.cin == 64 and d.cout == 64 and d.x_dtype == L.F32 and f64s >= (2 if packed else 1):
+            if d.cin == 64 and d.cout == 64 and d.z_dtype == d.x_dtype and f64s >= (2 if packed else 1):
                 return 'dp_fwd64s_kernel<true>' if d.pool_out else 'dp_fwd64s_kernel<false>'
             gemm = ',true' if d.pool_out else ',false'      # forward: fused pooling outputs
         return (f"dp_{kind}_kernel<{d.cin},{d.cout},{'16,32' if big else '8,16'},"

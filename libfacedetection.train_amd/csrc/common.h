@@ -298,13 +298,13 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 static inline int hip_status() { return -(int)hipGetLastError(); }
 
 // conv_fwd64.hip: the plain fp32 64 -> 64 forward unit (no packing, no fused pooling)
-int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream);
+int ACT_SUFFIX(launch_dp_fwd64s)(const YunetDP* d, hipStream_t stream);
 // conv_bwd16.hip: backward of the fp32 16 -> 16 unit (plain or pooled dy), z recomputed from x
 int launch_dp_bwd16s(const YunetDP* d, hipStream_t stream);
 // conv_fwd16.hip: forward of the fp32 16 -> 16 (plain | fused pooling) and 16 -> 64 units
-int launch_dp_fwd16s(const YunetDP* d, hipStream_t stream);
+int ACT_SUFFIX(launch_dp_fwd16s)(const YunetDP* d, hipStream_t stream);
 // conv_stem.hip: the fp32 stem on the matrix cores (forward; weight gradient with z recomputed from the image)
-int launch_stem_fwd_mma(const float* img, const float* w, const float* b, float* z, double* stats, int N, int H, int W,
-                        hipStream_t stream);
+int ACT_SUFFIX(launch_stem_fwd_mma)(const float* img, const float* w, const float* b, float* z, double* stats, int N, int H, int W,
+                                    hipStream_t stream);
 int launch_stem_bwd_mma(const float* img, const float* w, const float* b, const float* dy, const YunetBN* bn, float* partials,
                         int blocks, int N, int H, int W, hipStream_t stream);

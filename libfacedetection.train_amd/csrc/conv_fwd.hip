@@ -740,10 +740,8 @@ inline int ew_grid(long long total) {
 extern "C" int ACT_SUFFIX(yunet_stem_fwd)(const float* img, const float* w, const float* b, float* z,
                                           double* stats, int N, int H, int W, int cmid, void* stream) {
     if (cmid != 16 || (H & 1) || (W & 1)) return YUNET_EINVAL;
-#ifndef YUNET_ACT_BF16
-    // fp32 storage: the convolution as a matrix product on the matrix cores (conv_stem.hip)
-    if (yunet_options().stem_mma) return launch_stem_fwd_mma(img, w, b, z, stats, N, H, W, (hipStream_t)stream);
-#endif
+    // the convolution as a matrix product on the matrix cores (conv_stem.hip)
+    if (yunet_options().stem_mma) return ACT_SUFFIX(launch_stem_fwd_mma)(img, w, b, z, stats, N, H, W, (hipStream_t)stream);
     const int tiles = N * ((W / 2 + STEM_TW - 1) / STEM_TW) * ((H / 2 + STEM_TH - 1) / STEM_TH);
     // persistent grid = resident workgroups (158 VGPRs -> 3 waves/SIMD -> 3 per CU on 256 CUs)
     const int grid = tiles < 768 ? tiles : 768;
@@ -757,13 +755,11 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     if (d->z_dtype != YUNET_ACT_DTYPE && !(d->cout == 16 && d->z_dtype == YUNET_F32)) return YUNET_EINVAL;
     if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU) return YUNET_EINVAL;
-#ifndef YUNET_ACT_BF16
-    // fp32 units with 16 input channels: wave-streaming kernels (conv_fwd16.hip)
-    if (d->cin == 16 && (d->cout == 16 || (d->cout == 64 && !d->pool_out)) && d->z_dtype == YUNET_F32 && !d->prof && yunet_options().fwd16s &&
+    // units with 16 input channels: wave-streaming kernels (conv_fwd16.hip)
+    if (d->cin == 16 && (d->cout == 16 || (d->cout == 64 && !d->pool_out)) && d->z_dtype == YUNET_ACT_DTYPE && !d->prof && yunet_options().fwd16s &&
         (!d->pool_out || (yunet_dp_pool_fusion_ok(d->N, d->H, d->W, 16, 16) && d->out_bn.gamma && d->pool_idx &&
                           !(reinterpret_cast<uintptr_t>(d->pool_idx) & 3))))
-        return launch_dp_fwd16s(d, s);
-#endif
+        return ACT_SUFFIX(launch_dp_fwd16s)(d, s);
     if (d->pool_out) {
         // also write the raw max_pool2d winners + their window positions (fused pooling)
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_bn.gamma || !d->pool_idx ||   // (out_has_bn may be 0: eval())
@@ -771,9 +767,7 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
             return YUNET_EINVAL;
         if (d->cin == 16) return launch_dp_fwd<16, 16, 16, 32, false, true>(d, s);
         if (d->cin == 32) return launch_dp_fwd<32, 64, 8, 16, false, true>(d, s);
-#ifndef YUNET_ACT_BF16
-        if ((unsigned long long)d->prof < 64ull && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
-#endif
+        if ((unsigned long long)d->prof < 64ull && yunet_options().fwd64s && d->z_dtype == YUNET_ACT_DTYPE) return ACT_SUFFIX(launch_dp_fwd64s)(d, s);
         return launch_dp_fwd<64, 64, 8, 16, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \
@@ -783,16 +777,15 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     // 20x20 / 10x10 levels: packed canvas -- except the fp32 64 -> 64 units, which run on the wave-streaming kernel
     // (one or two 14-column strips per image; option fwd64s = 1 puts them back here: 20 x 20 0.0324 -> 0.0266 ms,
     // 10 x 10 0.0152 -> 0.0132 ms, profiles/r04_fwd_small.log)
-    if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout) && !(YUNET_ACT_DTYPE == YUNET_F32 && d->cout == 64 && yunet_options().fwd64s >= 2))
+    if (dp_use_pack(d->N, d->H, d->W, d->cin, d->cout) && !(d->cout == 64 && d->z_dtype == YUNET_ACT_DTYPE && yunet_options().fwd64s >= 2))
         return d->cout == 64 ? launch_dp_fwd<64, 64, 8, 16, true>(d, s) : launch_dp_fwd<64, 16, 8, 16, true>(d, s);
-#ifndef YUNET_ACT_BF16
     // the plain 64 -> 64 unit: wave-streaming kernel (conv_fwd64.hip); the phase-clock debug mode stays on the
     // tile kernel
-    #ifdef F64S_PROF
-    if (d->cin == 64 && d->cout == 64 && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
+#ifdef F64S_PROF
+    if (d->cin == 64 && d->cout == 64 && yunet_options().fwd64s) return ACT_SUFFIX(launch_dp_fwd64s)(d, s);
 #endif
-    if (d->cin == 64 && d->cout == 64 && (unsigned long long)d->prof < 64ull && yunet_options().fwd64s) return launch_dp_fwd64s(d, s);
-#endif
+    if (d->cin == 64 && d->cout == 64 && d->z_dtype == YUNET_ACT_DTYPE && (unsigned long long)d->prof < 64ull && yunet_options().fwd64s)
+        return ACT_SUFFIX(launch_dp_fwd64s)(d, s);
     DP_CASE(16, 16)
     DP_CASE(16, 32)
     DP_CASE(16, 64)

@@ -94,8 +94,9 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
 
     const int strips = (W + OUTW - 1) / OUTW, bands = (H + R - 1) / R;
     const int tasks_img = strips * bands, ntasks = d.N * tasks_img;
-    const unsigned xbytes = (unsigned)(H * W * CIN) * 4u, zbytes = (unsigned)(H * W * COUT) * 4u;
-    const unsigned pobytes = (unsigned)((H >> 1) * (W >> 1) * COUT) * 4u;
+    // activation storage of this build (common.h: act_t = float | bf16): x, z and the pooled winners
+    const unsigned xbytes = (unsigned)(H * W * CIN) * ACT_B, zbytes = (unsigned)(H * W * COUT) * ACT_B;
+    const unsigned poel = (unsigned)((H >> 1) * (W >> 1) * COUT), pobytes = poel * ACT_B;
     const int total_waves = (int)gridDim.x * WAVES;
 
     for (int task = first_tile() * WAVES + wid; task < ntasks; task += total_waves) {
@@ -103,10 +104,10 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
         const int band = rr / strips, strip = rr - band * strips;
         const int y0 = band * R, y1 = (y0 + R < H) ? y0 + R : H;
         const int xs = strip * OUTW - HALO;                   // image column of the strip's pixel 0
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
-        const auto r_po = __builtin_amdgcn_make_buffer_rsrc(d.pool_out + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0, POOL ? pobytes : 0u, 0x00020000);
-        const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0, POOL ? pobytes / 4 : 0u, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(d.z) + (size_t)n * d.z_img_stride, 0, zbytes, 0x00020000);
+        const auto r_po = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(d.pool_out) + (POOL ? (size_t)n * poel : (size_t)0), 0, POOL ? pobytes : 0u, 0x00020000);
+        const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOL ? (size_t)n * poel : (size_t)0), 0, POOL ? poel : 0u, 0x00020000);
         // layout C: bit k = pixel NSEG sg + k is an output pixel of this strip
         unsigned omask = 0;
 #pragma unroll
@@ -115,13 +116,12 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
             omask |= ((unsigned)(xs + j) < (unsigned)W && j >= HALO && j < PXW - HALO) ? (1u << k) : 0u;
         }
         auto colP = [&](int nt) { return xs + 16 * nt + l15; };
-        u32x4 lx[NT];
+        act_raw4 lx[NT];
         auto issue_x = [&](int y) {
             const bool yin = (unsigned)y < (unsigned)H;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                lx[nt] = __builtin_amdgcn_raw_buffer_load_b128(
-                    r_x, (yin && (unsigned)colP(nt) < (unsigned)W) ? (unsigned)((y * W + colP(nt)) * CIN + 4 * g) * 4u : xbytes, 0, 0);
+                lx[nt] = act_bufld4(r_x, (yin && (unsigned)colP(nt) < (unsigned)W) ? (unsigned)((y * W + colP(nt)) * CIN + 4 * g) * ACT_B : xbytes);
         };
         issue_x(y0 - 1);
         float ts0 = 0.0f, ts1 = 0.0f;                         // BN sums of the band: channel cc over the lane's output pixels
@@ -131,16 +131,16 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
             const bool xin = (unsigned)X < (unsigned)H;
             // ---- [P] a = T(x(X)); p(X) = W1 a + b1 -> slot A ------------------------------------------------------------
             {
-                u32x4 xr[NT];
+                float4 xr[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) xr[nt] = lx[nt];
+                for (int nt = 0; nt < NT; ++nt) xr[nt] = act_unpack(lx[nt]);
                 issue_x(X + 1);                // (the row past the band's last one is fetched and never used)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float a0 = fmaxf(fmaf(__uint_as_float(xr[nt][0]) - im.x, isc.x, ibt.x), relu_floor);
-                    const float a1 = fmaxf(fmaf(__uint_as_float(xr[nt][1]) - im.y, isc.y, ibt.y), relu_floor);
-                    const float a2 = fmaxf(fmaf(__uint_as_float(xr[nt][2]) - im.z, isc.z, ibt.z), relu_floor);
-                    const float a3 = fmaxf(fmaf(__uint_as_float(xr[nt][3]) - im.w, isc.w, ibt.w), relu_floor);
+                    const float a0 = fmaxf(fmaf(xr[nt].x - im.x, isc.x, ibt.x), relu_floor);
+                    const float a1 = fmaxf(fmaf(xr[nt].y - im.y, isc.y, ibt.y), relu_floor);
+                    const float a2 = fmaxf(fmaf(xr[nt].z - im.z, isc.z, ibt.z), relu_floor);
+                    const float a3 = fmaxf(fmaf(xr[nt].w - im.w, isc.w, ibt.w), relu_floor);
                     const bool ok = xin && (unsigned)colP(nt) < (unsigned)W;       // zero padding of the depthwise input
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -215,8 +215,8 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
                     const bool mine = (unsigned)colP(nt) < (unsigned)W && j >= HALO && j < PXW - HALO;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(slot_z + j * PST + 16 * mt + 4 * g);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, r_z, mine ? (unsigned)((q * W + colP(nt)) * COUT + 16 * mt + 4 * g) * 4u : zbytes, 0, 0);
+                        const float4 v = *reinterpret_cast<const float4*>(slot_z + j * PST + 16 * mt + 4 * g);
+                        act_bufst4(r_z, mine ? (unsigned)((q * W + colP(nt)) * COUT + 16 * mt + 4 * g) * ACT_B : zbytes, v);
                     }
                 }
                 if constexpr (POOL) {
@@ -225,10 +225,10 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
                         const int j = 2 * l15, col = xs + j;
                         const bool mine = (unsigned)(col + 1) < (unsigned)W && col >= 0 && j >= HALO && j < PXW - HALO;
                         const unsigned eq = (unsigned)(((q >> 1) * (W >> 1) + (col >> 1)) * COUT + 4 * g);
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(slot_a + l15 * PST + 4 * g);
+                        const float4 v = *reinterpret_cast<const float4*>(slot_a + l15 * PST + 4 * g);
                         const unsigned id = *reinterpret_cast<const unsigned*>(slot_i + l15 * 16 + 4 * g);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, r_po, mine ? eq * 4u : pobytes, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(id, r_pi, mine ? eq : pobytes, 0, 0);
+                        act_bufst4(r_po, mine ? eq * ACT_B : pobytes, v);
+                        __builtin_amdgcn_raw_buffer_store_b32(id, r_pi, mine ? eq : poel, 0, 0);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slots are free for the next row
@@ -280,6 +280,7 @@ int launch_fwd16s(const YunetDP* d, hipStream_t stream) {
         blocks_per_cu = nb > 3 ? 3 : nb;
     }
     if ((long long)d->H * d->W * COUT * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
+    if (d->x_dtype != YUNET_ACT_DTYPE || d->z_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     constexpr int HALO = POOL ? 2 : 1, OUTW = GG::PXW - 2 * HALO;
     int grid = 256 * blocks_per_cu;
     const int R = fwd16s_rows(d->N, d->H, d->W, OUTW, grid * f16s::WAVES, POOL);
@@ -292,8 +293,9 @@ int launch_fwd16s(const YunetDP* d, hipStream_t stream) {
 
 }  // namespace
 
-// conv_fwd.hip's dispatcher: fp32 units with 16 input channels and 16 or 64 output channels (fused pooling: 16 -> 16)
-int launch_dp_fwd16s(const YunetDP* d, hipStream_t stream) {
+// conv_fwd.hip's dispatcher: units with 16 input channels and 16 or 64 output channels (fused pooling: 16 -> 16); compiled
+// once per activation storage type (fp32 | -DYUNET_ACT_BF16: x, z and the pooled winners as bf16, same arithmetic)
+int ACT_SUFFIX(launch_dp_fwd16s)(const YunetDP* d, hipStream_t stream) {
     if (d->cout == 16) return d->pool_out ? launch_fwd16s<16, true>(d, stream) : launch_fwd16s<16, false>(d, stream);
     return launch_fwd16s<64, false>(d, stream);
 }

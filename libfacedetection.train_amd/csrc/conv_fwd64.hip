@@ -25,6 +25,11 @@
 //   * the pointwise GEMM runs on (rows + 2) x 16 pixels per band of `rows` x 14 outputs: x1.26 at 20-row bands
 //     instead of x1.5.
 // BN statistics: fp32 per lane over a band, fp64 in LDS across bands, one fp64 atomic per channel and workgroup.
+//
+// Compiled twice (common.h: act_t).  -DYUNET_ACT_BF16 (BASELINE configs[2], "bf16 fwd / fp32 grads"): x, z and the pooled
+// winners are stored as bf16 and the pointwise product is ONE bf16 matrix instruction per block on a = bf16(relu(bn(x)))
+// and bf16(W1) (fp32 accumulation) instead of the exact three-way split -- the arithmetic of the bf16 tile kernel
+// (conv_fwd.hip); depthwise, bias and BN sums (of the unrounded values) stay fp32.
 #include "common.h"
 
 namespace {
@@ -83,11 +88,14 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
         const int co = i / C, ci = i % C;
         const float w = d.w_pw[i];
         const __bf16 h = (__bf16)w;
+        const int at = co * C + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
+        s_w1p[at] = h;
+#ifndef YUNET_ACT_BF16
         const float r1 = w - (float)h;
         const __bf16 m = (__bf16)r1;
         const __bf16 l = (__bf16)(r1 - (float)m);
-        const int at = co * C + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
-        s_w1p[at] = h; s_w1p[C * C + at] = m; s_w1p[2 * C * C + at] = l;
+        s_w1p[C * C + at] = m; s_w1p[2 * C * C + at] = l;
+#endif
     }
     for (int i = tid; i < C * 9; i += NTHR) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
     if (tid < C) {
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
     float* pslot = s_p + wid * SLOT_FLOATS;
     const int strips = (W + TW - 1) / TW, bands = (H + R - 1) / R;
     const int tasks_img = strips * bands, ntasks = d.N * tasks_img;
-    const unsigned xbytes = (unsigned)(H * W * C) * 4u;
+    const unsigned xbytes = (unsigned)(H * W * C) * ACT_B;        // x and z: [H][W][64] in the activation storage type
     const int cq = l15, cgrp = g;                       // depthwise role of the lane: channel quad, column group
     const int total_waves = (int)gridDim.x * WAVES;
 
@@ -139,9 +147,9 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
         const int col = xs - 1 + l15;                                      // matrix role: input column of this lane
         const bool colv = (unsigned)col < (unsigned)W;
         const float cap = colv ? __builtin_inff() : 0.0f;
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(d.z + (size_t)n * d.z_img_stride, 0, xbytes, 0x00020000);
-        const unsigned xlane = colv ? (unsigned)(col * C + 8 * g) * 4u : xbytes;       // out of the image: reads 0
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(d.z) + (size_t)n * d.z_img_stride, 0, xbytes, 0x00020000);
+        const unsigned xlane = colv ? (unsigned)(col * C + 8 * g) * ACT_B : xbytes;       // out of the image: reads 0
         const float* biasp = s_b1 + (colv ? C : 0) + 4 * g;
         // depthwise columns of this lane: two adjacent pairs, strip-local c = 2 cgrp + 8 (j >> 1) + (j & 1); their store
         // offsets and masks (a pair shares two of its three input columns: 8 LDS reads per row instead of 12)
@@ -151,32 +159,37 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
         for (int j = 0; j < 4; ++j) {
             const int c = 2 * cgrp + 8 * (j >> 1) + (j & 1), xc = xs + c;
             const bool v = c < TW && xc < W;
-            zlane[j] = v ? (unsigned)(xc * C + cq * 4) * 4u : xbytes;     // dropped by the range check
+            zlane[j] = v ? (unsigned)(xc * C + cq * 4) * ACT_B : xbytes;     // dropped by the range check
             fm[j] = v ? 1.0f : 0.0f;
         }
         // fused pooling: window (row pair, column pair q) of this lane -> element offset in pool_out / pool_idx
-        const unsigned pobytes = (unsigned)((H >> 1) * (W >> 1) * C) * 4u;
-        const auto r_po = __builtin_amdgcn_make_buffer_rsrc(d.pool_out + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0,
+        const unsigned poel = (unsigned)((H >> 1) * (W >> 1) * C), pobytes = poel * ACT_B;
+        const auto r_po = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(d.pool_out) + (POOL ? (size_t)n * poel : (size_t)0), 0,
                                                             POOL ? pobytes : 0u, 0x00020000);
-        const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOL ? (size_t)n * (pobytes / 4) : (size_t)0), 0,
-                                                            POOL ? pobytes / 4 : 0u, 0x00020000);
+        const auto r_pi = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOL ? (size_t)n * poel : (size_t)0), 0,
+                                                            POOL ? poel : 0u, 0x00020000);
         unsigned plane[2] = {0, 0};
         if constexpr (POOL) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * cgrp + 8 * q, xc = xs + c;
-                plane[q] = (c < TW && xc < W) ? (unsigned)((xc >> 1) * C + cq * 4) : pobytes;     // elements; dropped when out of range
+                plane[q] = (c < TW && xc < W) ? (unsigned)((xc >> 1) * C + cq * 4) : poel;     // elements; dropped when out of range
             }
         }
         const int rs = y0 > 0 ? y0 - 1 : 0, re = y1 < H ? y1 : H - 1;
         u32x4 xr[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
         auto issue = [&](int y) {
             if (abl & 8) return;
-            const unsigned o = xlane + (unsigned)(y * W * C) * 4u;
+            const unsigned o = xlane + (unsigned)(y * W * C) * ACT_B;
+#ifdef YUNET_ACT_BF16
+            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, 0);          // 8 bf16 channels of block 0
+            xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 64, 0, 0);     // ... of block 1
+#else
             xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, 0);
             xr[1] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 16, 0, 0);
             xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 128, 0, 0);
             xr[3] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 144, 0, 0);
+#endif
         };
         issue(rs);
         const float4 b2 = *reinterpret_cast<const float4*>(s_b2 + cq * 4);
@@ -190,11 +203,10 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
         // a finished output row: z to HBM, BN partial sums, fused pooling
         float4 prev[4];
         auto emit_row = [&](int yy, const float4 (&dn)[4]) {
-            const unsigned zrow = (unsigned)(yy * W * C) * 4u;
+            const unsigned zrow = (unsigned)(yy * W * C) * ACT_B;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (!(abl & 4))
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&dn[j]), r_z, zrow + zlane[j], 0, 0);
+                if (!(abl & 4)) act_bufst4(r_z, zrow + zlane[j], dn[j]);
                 const float m = fm[j];
                 const float vx = dn[j].x * m, vy = dn[j].y * m, vz = dn[j].z * m, vw = dn[j].w * m;
                 ts[0] += vx; ts[1] += vy; ts[2] += vz; ts[3] += vw;
@@ -225,9 +237,8 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
                             v[i] = right ? vr : vl;
                             jw |= (right ? jr : jl) << (8 * i);
                         }
-                        const unsigned eq = plane[q] == pobytes ? pobytes : prow + plane[q];
-                        const float4 pvv = make_float4(v[0], v[1], v[2], v[3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&pvv), r_po, eq * 4u, 0, 0);
+                        const unsigned eq = plane[q] == poel ? poel : prow + plane[q];
+                        act_bufst4(r_po, eq * ACT_B, make_float4(v[0], v[1], v[2], v[3]));
                         __builtin_amdgcn_raw_buffer_store_b32(jw, r_pi, eq, 0, 0);
                     }
                 }
@@ -248,6 +259,19 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
                 const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
                 const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
                 float a[8];
+#ifdef YUNET_ACT_BF16
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // dword q of the load: channels 2 q (low half), 2 q + 1 (high half)
+                    const unsigned w2 = xr[2 * kb][q];
+                    a[2 * q] = med3(fmaf(__uint_as_float(w2 << 16), sc[2 * q], sh[2 * q]), relu_floor, cap);
+                    a[2 * q + 1] = med3(fmaf(__uint_as_float(w2 & 0xffff0000u), sc[2 * q + 1], sh[2 * q + 1]), relu_floor, cap);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bh[kb][q] = pack_bf16x2(a[2 * q], a[2 * q + 1]);        // a = bf16(relu(bn(x))): the one operand of this build
+                    bm[kb][q] = bl[kb][q] = 0u;
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     a[e] = med3(fmaf(__uint_as_float(xr[2 * kb][e]), sc[e], sh[e]), relu_floor, cap);
@@ -262,6 +286,7 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
                     const unsigned lb = pack_bf16x2(r0 - __uint_as_float(mb << 16), r1 - __uint_as_float(mb & 0xffff0000u));
                     bh[kb][q] = hb; bm[kb][q] = mb; bl[kb][q] = lb;
                 }
+#endif
             }
             F64S_STAMP(1)
             // the registers are free again: the next row is in flight under this row's arithmetic
@@ -280,8 +305,12 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
                 const int kb = i >> 2, co = (i & 3) * 16 + l15;
                 const __bf16* wp = s_w1p + co * C + (((4 * kb + g) ^ (co & (NCH - 1))) << 3);
                 f[0] = *reinterpret_cast<const u32x4*>(wp);
+#ifdef YUNET_ACT_BF16
+                f[1] = f[2] = f[0];
+#else
                 f[1] = *reinterpret_cast<const u32x4*>(wp + C * C);
                 f[2] = *reinterpret_cast<const u32x4*>(wp + 2 * C * C);
+#endif
             };
             if (!(abl & 1)) {
                 u32x4 wf[2][3];
@@ -296,11 +325,13 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
                     const bf16x8_t Wh = __builtin_bit_cast(bf16x8_t, wf[i & 1][0]), Wm = __builtin_bit_cast(bf16x8_t, wf[i & 1][1]),
                                    Wl = __builtin_bit_cast(bf16x8_t, wf[i & 1][2]);
                     f32x4 c = acc[nt];                                   // small terms first
+#ifndef YUNET_ACT_BF16
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Bl, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wl, Bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wm, Bm, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Bm, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wm, Bh, c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh, Bh, c, 0, 0, 0);
                     acc[nt] = c;
                     __builtin_amdgcn_sched_barrier(0);
@@ -416,6 +447,7 @@ static int launch_fwd64s(const YunetDP* d, hipStream_t stream) {
     return hip_status();
 }
 
-int launch_dp_fwd64s(const YunetDP* d, hipStream_t stream) {
+int ACT_SUFFIX(launch_dp_fwd64s)(const YunetDP* d, hipStream_t stream) {
+    if (d->x_dtype != YUNET_ACT_DTYPE || d->z_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     return d->pool_out ? launch_fwd64s<true>(d, stream) : launch_fwd64s<false>(d, stream);
 }

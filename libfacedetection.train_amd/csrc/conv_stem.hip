@@ -93,7 +93,8 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
 
     const int strips = (Wo + PXO - 1) / PXO, bands = (Ho + R - 1) / R;
     const int tasks_img = strips * bands, ntasks = N * tasks_img;
-    const unsigned img_bytes = (unsigned)(3 * H * W) * 4u, zbytes = (unsigned)(Ho * Wo * C) * 4u;
+    // forward: z in the activation storage type of this build (common.h: act_t); backward: dy is fp32 in every build
+    const unsigned img_bytes = (unsigned)(3 * H * W) * 4u, zbytes = (unsigned)(Ho * Wo * C) * (BWD ? 4u : ACT_B);
     const int total_waves = (int)gridDim.x * WAVES;
 
     for (int task = first_tile() * WAVES + wid; task < ntasks; task += total_waves) {
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
         const int y0 = band * R, y1 = (y0 + R < Ho) ? y0 + R : Ho;
         const int xo0 = strip * PXO;
         const auto r_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img) + (size_t)n * 3 * H * W, 0, img_bytes, 0x00020000);
-        const auto r_z = __builtin_amdgcn_make_buffer_rsrc((BWD ? const_cast<float*>(dy) : z) + (size_t)n * Ho * Wo * C, 0, zbytes, 0x00020000);
+        const auto r_z = BWD ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy) + (size_t)n * Ho * Wo * C, 0, zbytes, 0x00020000)
+                             : __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(z) + (size_t)n * Ho * Wo * C, 0, zbytes, 0x00020000);
         // an image row of the strip = 34 aligned column pairs (lanes 0 .. 33); outside the image: offset past the end, reads 0
         const int colp = 2 * xo0 - 2 + 2 * lane;
         const bool colok = lane < COLS / 2 && colp >= 0 && colp < W;
@@ -178,8 +180,7 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
                 for (int t = 0; t < 2; ++t) {
                     const int ox = xo0 + 16 * t + l15;
                     const bool ok = ox < Wo;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&zt[t]), r_z,
-                                                           ok ? (unsigned)((oy * Wo + ox) * C + 4 * g) * 4u : zbytes, 0, 0);
+                    act_bufst4(r_z, ok ? (unsigned)((oy * Wo + ox) * C + 4 * g) * ACT_B : zbytes, make_float4(zt[t][0], zt[t][1], zt[t][2], zt[t][3]));
                     const float m = ok ? 1.0f : 0.0f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -273,10 +274,11 @@ int stem_rows(int N, int Ho, int Wo, int waves) {
 
 }  // namespace
 
-// conv_fwd.hip / conv_bwd.hip dispatch here for fp32 activation storage (option stem_mma).  Grids: forward 256 CUs x 3
-// workgroups; backward = the rows of wgrad_partials (yunet_stem_bwd_blocks): every workgroup writes its row.
-int launch_stem_fwd_mma(const float* img, const float* w, const float* b, float* z, double* stats, int N, int H, int W,
-                        hipStream_t stream) {
+// conv_fwd.hip / conv_bwd.hip dispatch here (option stem_mma).  The forward is compiled once per activation storage type (fp32 |
+// -DYUNET_ACT_BF16: z stored as bf16, BN sums of the unrounded values); the weight gradient with its recomputed z is fp32-storage
+// only.  Grids: forward 256 CUs x 3 workgroups; backward = the rows of wgrad_partials (yunet_stem_bwd_blocks).
+int ACT_SUFFIX(launch_stem_fwd_mma)(const float* img, const float* w, const float* b, float* z, double* stats, int N, int H, int W,
+                                    hipStream_t stream) {
     if ((long long)3 * H * W * 4 >= (1ll << 31)) return YUNET_EINVAL;
     const int grid = 768;
     const int R = stem_rows(N, H / 2, W / 2, grid * stm::WAVES);
@@ -284,6 +286,7 @@ int launch_stem_fwd_mma(const float* img, const float* w, const float* b, float*
                        YunetBN{}, (float*)nullptr, N, H, W, R);
     return hip_status();
 }
+#ifndef YUNET_ACT_BF16
 int launch_stem_bwd_mma(const float* img, const float* w, const float* b, const float* dy, const YunetBN* bn, float* partials,
                         int blocks, int N, int H, int W, hipStream_t stream) {
     if ((long long)3 * H * W * 4 >= (1ll << 31)) return YUNET_EINVAL;
@@ -292,3 +295,4 @@ int launch_stem_bwd_mma(const float* img, const float* w, const float* b, const 
                        *bn, partials, N, H, W, R);
     return hip_status();
 }
+#endif

@@ -40,11 +40,12 @@ def stats_of(z):
 
 @pytest.fixture
 def tile_kernels():
-    """The kernel-level claims below are about ONE source compiled twice (fp32 / bf16 activation storage): the fp32 side
-    must run the same tile kernels the bf16 build runs, not the fp32-only wave-streaming rebuilds of round 4 (other
-    summation order; conv_bwd16.hip recomputes z instead of reading the rounded one)."""
+    """The kernel-level claims below are about ONE source compiled twice (fp32 / bf16 activation storage).  The forward
+    kernels are (tile and wave-streaming kernels alike); two fp32-only rebuilds of round 4 are not: conv_bwd16.hip
+    RECOMPUTES z instead of reading the rounded one, and the stem weight gradient on the matrix cores does the same --
+    for the backward comparisons the fp32 side runs the tile kernels the bf16 build runs."""
     import yunet_amd._lib as L
-    prev = {o: L.set_option(o, 0) for o in ('fwd16s', 'bwd16s', 'stem_mma')}
+    prev = {o: L.set_option(o, 0) for o in ('bwd16s',)}
     yield
     for o, v in prev.items():
         L.set_option(o, v)
