@@ -246,9 +246,8 @@ def op_name(op, L):
              L.OP_BN_RUNNING: 'bn_running_kernel', L.OP_BN_PARAM_GRAD: 'bn_param_grad_kernel',
              L.OP_REDUCE_PARTIALS: 'reduce_partials_kernel', L.OP_MEMSET: 'memset',
              L.OP_REDUCE_BATCH: 'reduce_partials_batch_kernel', L.OP_BN_BATCH: 'bn_batch_kernel'}
-    if (op.opcode in (L.OP_STEM_FWD, L.OP_STEM_BWD) and int(os.environ.get('YUNET_STEM_MMA', '1'))
-            and (op.opcode == L.OP_STEM_FWD or op.i[11] != L.BF16)):
-        # round 4: the stem as matrix products (csrc/conv_stem.hip); the fp32-storage backward recomputes z from the image
+    if op.opcode in (L.OP_STEM_FWD, L.OP_STEM_BWD) and int(os.environ.get('YUNET_STEM_MMA', '1')):
+        # round 4: the stem as matrix products (csrc/conv_stem.hip); the backward recomputes z from the image
         return 'stem_mma_kernel<false>' if op.opcode == L.OP_STEM_FWD else 'stem_mma_kernel<true>'
     if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):
         # the template instance the C dispatcher picks (csrc/conv_fwd.hip / conv_bwd.hip / common.h):
@@ -270,7 +269,7 @@ def op_name(op, L):
                 return f"dp_bwd64_kernel<{nw},{'true' if packed else 'false'},{'true' if d.pool_idx else 'false'}>"
             # round 4: the fp32 16 -> 16 unit on the big maps runs on the wave-streaming kernel that recomputes z
             # (csrc/conv_bwd16.hip) unless YUNET_BWD16S=0
-            if (big and d.x_dtype == L.F32 and d.out_has_bn and d.dx and not d.accumulate_dx
+            if (big and d.out_has_bn and d.dx and not d.accumulate_dx
                     and int(os.environ.get('YUNET_BWD16S', '1'))):
                 return f"dp_bwd16s_kernel<{'true' if d.pool_idx else 'false'}>"
             gemm = ',0'

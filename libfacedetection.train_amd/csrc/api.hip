@@ -210,8 +210,8 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
                                     stream);
                 break;
             case YUNET_OP_STEM_BWD:
-                // p[4], p[5] = the stem's weights / bias: with fp32 storage the weight gradient recomputes z from the image
-                if (o.i[11] != YUNET_BF16 && o.p[4] && o.p[5] && yunet_options().stem_mma) {
+                // p[4], p[5] = the stem's weights / bias: the weight gradient recomputes z from the image
+                if (o.p[4] && o.p[5] && yunet_options().stem_mma) {        // (reads the image and dy only: any activation storage type)
                     rc = yunet_stem_bwd_rz((const float*)o.p[0], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[2],
                                            &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], stream);
                     break;

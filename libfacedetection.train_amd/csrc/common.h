@@ -300,7 +300,7 @@ static inline int hip_status() { return -(int)hipGetLastError(); }
 // conv_fwd64.hip: the plain fp32 64 -> 64 forward unit (no packing, no fused pooling)
 int ACT_SUFFIX(launch_dp_fwd64s)(const YunetDP* d, hipStream_t stream);
 // conv_bwd16.hip: backward of the fp32 16 -> 16 unit (plain or pooled dy), z recomputed from x
-int launch_dp_bwd16s(const YunetDP* d, hipStream_t stream);
+int ACT_SUFFIX(launch_dp_bwd16s)(const YunetDP* d, hipStream_t stream);
 // conv_fwd16.hip: forward of the fp32 16 -> 16 (plain | fused pooling) and 16 -> 64 units
 int ACT_SUFFIX(launch_dp_fwd16s)(const YunetDP* d, hipStream_t stream);
 // conv_stem.hip: the fp32 stem on the matrix cores (forward; weight gradient with z recomputed from the image)

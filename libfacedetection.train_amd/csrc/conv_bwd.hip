@@ -2182,14 +2182,12 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
         d->wgrad_blocks != yunet_dp_bwd_blocks(d->N, d->H, d->W, d->cin, d->cout))
         return YUNET_EINVAL;   // the partial buffer must have exactly the rows the grid writes
     if (d->in_transform != YUNET_T_IDENTITY && d->in_transform != YUNET_T_BNRELU) return YUNET_EINVAL;
-#ifndef YUNET_ACT_BF16
     // the 16 -> 16 unit on the 160 x 160 / 80 x 80 levels: wave-streaming kernel that recomputes z from x instead of
     // reading it (conv_bwd16.hip); same grid and partial rows as the tile kernel it replaces
     if (d->cin == 16 && d->cout == 16 && dp_bwd_big_tile(d->H, d->W, 16, 16) && d->out_has_bn && d->dx && !d->accumulate_dx &&
         !d->prof && yunet_options().bwd16s &&
         (!d->pool_idx || (yunet_dp_pool_fusion_ok(d->N, d->H, d->W, 16, 16) && !(reinterpret_cast<uintptr_t>(d->pool_idx) & 3))))
-        return launch_dp_bwd16s(d, s);
-#endif
+        return ACT_SUFFIX(launch_dp_bwd16s)(d, s);
     if (d->pool_idx) {
         // dy is the pooled gradient + argmax bytes (max_pool2d backward while staging)
         if (!yunet_dp_pool_fusion_ok(d->N, d->H, d->W, d->cin, d->cout) || !d->out_has_bn) return YUNET_EINVAL;

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
 
     const int strips = (W + OUTW - 1) / OUTW, bands = (H + R - 1) / R;
     const int tasks_img = strips * bands, ntasks = d.N * tasks_img;
-    const unsigned xbytes = (unsigned)(H * W * C) * 4u;
+    // x in the activation storage type of this build (common.h: act_t); dy and dx are fp32 in every build
+    const unsigned xbytes = (unsigned)(H * W * C) * ACT_B, gbytes = (unsigned)(H * W * C) * 4u;
     const int Wq = W >> 1;
     const unsigned pooledbytes = (unsigned)((H >> 1) * Wq * C) * 4u;
     const int total_waves = (int)gridDim.x * WAVES;
@@ -136,11 +137,11 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
         const int band = rr / strips, strip = rr - band * strips;
         const int y0 = band * R, y1 = (y0 + R < H) ? y0 + R : H;
         const int xs = strip * OUTW - HALO;                  // image column of the strip's pixel 0
-        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
-        const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(d.dx + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + (size_t)n * d.x_img_stride, 0, xbytes, 0x00020000);
+        const auto r_dx = __builtin_amdgcn_make_buffer_rsrc(d.dx + (size_t)n * d.x_img_stride, 0, gbytes, 0x00020000);
         const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(d.dy) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)n * d.z_img_stride), 0,
-            POOLDY ? pooledbytes : xbytes, 0x00020000);
+            POOLDY ? pooledbytes : gbytes, 0x00020000);
         const auto r_id = __builtin_amdgcn_make_buffer_rsrc(d.pool_idx + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0,
                                                             POOLDY ? pooledbytes / 4u : 0u, 0x00020000);
         // layout P geometry, re-derived where it is used: pixel 16 t + l15 is image column xs + 16 t + l15
@@ -159,14 +160,14 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
             cmask |= v ? (1u << k) : 0u;
             omask |= (v && j >= HALO && j < PXW - HALO) ? (1u << k) : 0u;
         }
-        u32x4 lx[2], ldy[2];               // the next row of x | dy in flight (layout P)
+        act_raw4 lx[2];                    // the next row of x | dy in flight (layout P)
+        u32x4 ldy[2];
         unsigned lid[2];                   // POOLDY: the four position bytes of the lane's channel quad
         auto issue_x = [&](int y) {
             const bool yin = (unsigned)y < (unsigned)H;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                lx[t] = __builtin_amdgcn_raw_buffer_load_b128(
-                    r_x, (yin && colvP(t)) ? (unsigned)((y * W + colP(t)) * C + 4 * g) * 4u : xbytes, 0, 0);
+                lx[t] = act_bufld4(r_x, (yin && colvP(t)) ? (unsigned)((y * W + colP(t)) * C + 4 * g) * ACT_B : xbytes);
         };
         auto issue_dy = [&](int y) {
             const bool yin = (unsigned)y < (unsigned)H;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
                     ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, 0);
                     lid[t] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
                 } else {
-                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? (unsigned)((y * W + colP(t)) * C + 4 * g) * 4u : xbytes, 0, 0);
+                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? (unsigned)((y * W + colP(t)) * C + 4 * g) * 4u : gbytes, 0, 0);
                 }
             }
         };
@@ -195,15 +196,16 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
                 float im[4], isc[4], ibt[4], b1q[4];
                 ld4(s_in + gq, im); ld4(s_in + C + gq, isc); ld4(s_in + 2 * C + gq, ibt); ld4(s_b1 + gq, b1q);
                 float* rx = ring_x + ring * 512;
-                const u32x4 xr[2] = {lx[0], lx[1]};
+                const float4 xr[2] = {act_unpack(lx[0]), act_unpack(lx[1])};
                 issue_x(X + 1);            // (the row past the band's last one is fetched and never used)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    *reinterpret_cast<u32x4*>(rx + t * 256 + lane * 4) = xr[t];
+                    *reinterpret_cast<float4*>(rx + t * 256 + lane * 4) = xr[t];
+                    const float xv[4] = {xr[t].x, xr[t].y, xr[t].z, xr[t].w};
                     f32x4 acc = {b1q[0], b1q[1], b1q[2], b1q[3]};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const float a = fmaxf(fmaf(__uint_as_float(xr[t][s]) - im[s], isc[s], ibt[s]), relu_floor);
+                        const float a = fmaxf(fmaf(xv[s] - im[s], isc[s], ibt[s]), relu_floor);
                         acc = mfma16(w1a[s], a, acc);
                     }
                     const bool ok = xin && colvP(t);          // zero padding of the depthwise input
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_dx,
-                                                           ownP(t) ? (unsigned)((r * W + colP(t)) * C + gq) * 4u : xbytes, 0, 0);
+                                                           ownP(t) ? (unsigned)((r * W + colP(t)) * C + gq) * 4u : gbytes, 0, 0);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -466,8 +468,11 @@ int launch_bwd16s(const YunetDP* d, hipStream_t stream) {
 
 }  // namespace
 
-// conv_bwd.hip's dispatcher: the fp32 16 -> 16 unit on maps of the big-tile class, followed by BatchNorm, with a
-// plain (non-accumulating) dx.  d->z is NOT read: it must be this unit's forward output for d->x and the weights.
-int launch_dp_bwd16s(const YunetDP* d, hipStream_t stream) {
+// conv_bwd.hip's dispatcher: the 16 -> 16 unit on maps of the big-tile class, followed by BatchNorm, with a plain
+// (non-accumulating) dx.  d->z is NOT read: it must be this unit's forward output for d->x and the weights.  Compiled once
+// per activation storage type: with bf16 storage x is read as bf16 and z is recomputed from it in fp32 -- the UNROUNDED z
+// the BatchNorm sums were taken from (the tile kernel reads the rounded one).
+int ACT_SUFFIX(launch_dp_bwd16s)(const YunetDP* d, hipStream_t stream) {
+    if (d->x_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     return d->pool_idx ? launch_bwd16s<true>(d, stream) : launch_bwd16s<false>(d, stream);
 }

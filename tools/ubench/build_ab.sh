@@ -18,7 +18,7 @@ while [ $# -ge 2 ]; do
   $HIPCC $FLAGS $extra -c $CSRC/conv_bwd16.hip -o /tmp/conv_bwd16_$name.o &
   wait
   $HIPCC --offload-arch=gfx950 -shared -fPIC $CSRC/loss_step.o /tmp/conv_fwd_$name.o /tmp/conv_fwd64_$name.o /tmp/conv_bwd_$name.o /tmp/conv_bwd16_$name.o \
-      $CSRC/conv_fwd_bf16.o $CSRC/conv_bwd_bf16.o $CSRC/conv_fwd16_bf16.o $CSRC/conv_fwd64_bf16.o $CSRC/conv_stem_bf16.o $CSRC/augment.o $CSRC/detect.o $CSRC/collective.o $CSRC/conv_stem.o $CSRC/conv_fwd16.o $CSRC/api.o \
+      $CSRC/conv_fwd_bf16.o $CSRC/conv_bwd_bf16.o $CSRC/conv_fwd16_bf16.o $CSRC/conv_bwd16_bf16.o $CSRC/conv_fwd64_bf16.o $CSRC/conv_stem_bf16.o $CSRC/augment.o $CSRC/detect.o $CSRC/collective.o $CSRC/conv_stem.o $CSRC/conv_fwd16.o $CSRC/api.o \
       -o $ROOT/tools/ubench/libyunet_$name.so
   echo built libyunet_$name.so
 done
