@@ -147,6 +147,14 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_compact_kernel(
         bool valid = false;
         VRec rec;
         if (p < P) {
+            // the prior's head outputs go in flight before the region tests (only valid priors use them: the load used to sit
+            // behind the loop over the GTs, one exposed memory latency per chunk)
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 b = make_float2(0.f, 0.f);
+            if (!pre_scores) {
+                a = *reinterpret_cast<const float4*>(fl + (size_t)p * 16);
+                b = *reinterpret_cast<const float2*>(fl + (size_t)p * 16 + 4);
+            }
             float px, py, s;
             prior_of(L, p, px, py, s);
             const float cx = px + s * 0.5f, cy = py + s * 0.5f;
@@ -167,8 +175,6 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_compact_kernel(
                 rec.cls_cost = -fmaxf(logf(sqrtf(pre_scores[(size_t)n * P + p])), -100.0f);
                 rec.cx = cx; rec.cy = cy; rec.s = s;
             } else if (valid) {
-                const float4 a = *reinterpret_cast<const float4*>(fl + (size_t)p * 16);
-                const float2 b = *reinterpret_cast<const float2*>(fl + (size_t)p * 16 + 4);
                 // a = cls, dx, dy, dw ; b = dh, obj
                 const float bx = a.y * s + px, by = a.z * s + py;
                 const float bw = expf(a.w) * s, bh = expf(b.x) * s;
@@ -237,8 +243,10 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
         tc[i] = 3.0e38f;
         tv[i] = 0x7fffffff;
     }
+    VRec nxt = rec[lane < V ? lane : 0];               // the next record is in flight while one is ranked
     for (int v = lane; v < V; v += 64) {
-        const VRec r = rec[v];
+        const VRec r = nxt;
+        if (v + 64 < V) nxt = rec[v + 64];
         float iou = iou_of(r.x1, r.y1, r.x2, r.y2, gt);
         const bool both = in_gt_box(r.cx, r.cy, gt) && in_gt_center(r.cx, r.cy, r.s, radius, gt);
         float c = cost_of(r.cls_cost, iou, both, cw);

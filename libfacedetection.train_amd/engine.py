@@ -470,6 +470,10 @@ class Plan:
                                                             self.bn_table_bb, len(rb_b))
                 self.c_bwd_a = self._carray(self.bwd_a)
                 self.c_bwd_b = self._carray(self.bwd_b)
+                # one GPU: segment A's kernels alone + its reduction as a list of its own, which then runs on the side
+                # stream under the kernels of segment B (engine.backward)
+                self.c_bwd_a_k = self._carray(self.bwd_a[:ops_a])
+                self.c_tail_a = self._carray(self.bwd_a[ops_a:])
                 self.split_off, self.split_ops = split_off, ops_a
 
         # ---- eval(): the same conv-stack launches with BatchNorm on the running statistics
@@ -706,6 +710,7 @@ class Plan:
             elif self.split_off is not None:          # the two-segment copy of the backward list
                 if idx < self.split_ops:
                     self.c_bwd_a[idx].p[0] = ptr
+                    self.c_bwd_a_k[idx].p[0] = ptr
                 else:
                     self.c_bwd_b[idx - self.split_ops].p[0] = ptr
 
@@ -724,6 +729,7 @@ class YuNetEngine:
         self.plan = None
         self.always_bucket = False      # tests: run the two-segment backward + collectives at world size 1
         self.use_lanes = False          # head chains of the coarser levels on executor side streams (Plan.__init__)
+        self.overlap_reduce = os.environ.get('YUNET_OVERLAP_REDUCE', '1') != '0'     # one GPU: see backward()
         # comm_timing: events around the three collectives of a step (num_pos | bucket A on the side stream |
         # bucket B + logged scalars) and around the final wait for the side stream; comm_report() turns them
         # into milliseconds per step, split into EXPOSED (on the launch stream, nothing to hide behind) and
@@ -859,6 +865,18 @@ class YuNetEngine:
         if plan.deferred:
             # x the deferred 1 / num_total of the cls | box | obj channels (written by loss_finalize)
             torch.mul(plan.dy_up, plan.dy_norm, out=plan.dy_scale)
+        if (self.world_size <= 1 and not self.always_bucket) and plan.split_off is not None and self.overlap_reduce:
+            # one GPU: the weight-gradient reduction + BN parameter gradients of segment A (head, neck, late backbone
+            # stages: ~85 % of the parameters, 44 us as one launch at the end of backward) on the side stream, under the
+            # backward kernels of the early, high-resolution stages
+            main, side = torch.cuda.current_stream(), self._comm_stream()
+            self._exec(plan.c_bwd_a_k, 'yunet_exec(bwd_a kernels)')
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._exec(plan.c_tail_a, 'yunet_exec(bwd_a reduction)')
+            self._exec(plan.c_bwd_b, 'yunet_exec(bwd_b)')
+            main.wait_stream(side)
+            return
         if (self.world_size <= 1 and not self.always_bucket) or plan.split_off is None:
             self._exec(plan.c_bwd, 'yunet_exec(bwd)')
             self.allreduce_grads()
