@@ -1,7 +1,7 @@
 // conv_bwd16.hip -- backward of the 16 -> 16 ConvDPUnit (yunet_layer.py:30-36; autograd in the reference) as a
 // WAVE-STREAMING kernel that RECOMPUTES the unit's raw output z instead of reading it.
 //
-// Why (profiles/r04_pmc_traffic.json): the tile kernel dp_bwd_kernel<16,16,16,32,...> moves
+// Why (profiles/r03_pmc_traffic.json): the tile kernel dp_bwd_kernel<16,16,16,32,...> moves
 // 1.40 GB per 160 x 160 launch for 0.97 GB of unit-boundary bytes -- the BatchNorm backward is two-pass, so next to
 // dy it reads the whole output z a second time (x1.45) -- on one 512-thread workgroup per CU with seven barriers
 // per tile.  For a 16-channel input the forward is cheap enough to repeat: p = W1 a + b1 is 16 x 16 per pixel on
