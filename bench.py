@@ -349,11 +349,23 @@ def profile_ops(eng, reps=3):
 
 
 def gpu_clock_mhz(index=0):
-    """Current shader clock of the GPU in MHz (the starred level of pp_dpm_sclk), None where sysfs does not say."""
+    """Current shader clock in MHz (the starred level of pp_dpm_sclk), None where sysfs does not say.  The card numbering of
+    /sys/class/drm is not the HIP device numbering (some boxes list another adapter first): on a one-GPU box the busy GPU
+    is the card with the highest current level, with several GPUs the index-th card that exposes the file."""
     import glob
-    cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
-    if not cards:
+    vals = []
+    for path in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+        try:
+            for line in open(path):
+                if line.rstrip().endswith('*'):
+                    vals.append(int(''.join(ch for ch in line.split(':', 1)[1] if ch.isdigit())))
+                    break
+        except Exception:
+            pass
+    if not vals:
         return None
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    return vals[min(index, len(vals) - 1)] if world > 1 else max(vals)
     try:
         for line in open(cards[min(index, len(cards) - 1)]):
             if line.rstrip().endswith('*'):
