@@ -117,11 +117,18 @@ def op_bytes(op, L):
     if oc in (L.OP_POOL_FWD, L.OP_POOL_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
         i, o = n * h * w * c, n * h * w * c // 4
-        return (i + o) * ab if oc == L.OP_POOL_FWD else i * ab + i * 4 + o * 4
+        if oc == L.OP_POOL_FWD:
+            return (i + o) * ab
+        # backward: z, the pooled gradient, dx written (+ the merge's share of a pyramid tap read, when fused: p[3])
+        return i * ab + i * 4 + o * 4 + (i * 4 if op.p[3] else 0)
     if oc in (L.OP_UPADD_FWD, L.OP_UPADD_BWD):
         n, h, w, c = op.i[0], op.i[1], op.i[2], op.i[3]
         a, b = n * h * w * c, n * h * w * c // 4
-        return (a + b + a) * ab if oc == L.OP_UPADD_FWD else (a + b) * ab + (a + b) * 4 + a * 4
+        if oc == L.OP_UPADD_FWD:
+            return (a + b + a) * ab
+        if not op.p[3]:          # the fine tensor's share is applied by pool_bwd: dout read, zb read, dxb written
+            return a * 4 + b * ab + b * 4
+        return (a + b) * ab + (a + b) * 4 + a * 4
     if oc == L.OP_LOSS:
         return op.i[0] * op.i[1] * 16 * 4 * 2
     if oc == L.OP_ASSIGN:
@@ -366,13 +373,6 @@ def gpu_clock_mhz(index=0):
         return None
     world = int(os.environ.get('WORLD_SIZE', 1))
     return vals[min(index, len(vals) - 1)] if world > 1 else max(vals)
-    try:
-        for line in open(cards[min(index, len(cards) - 1)]):
-            if line.rstrip().endswith('*'):
-                return int(''.join(ch for ch in line.split(':', 1)[1] if ch.isdigit()))
-    except Exception:
-        pass
-    return None
 
 
 def plan_reference_graph_bytes(eng):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 7
+#define YUNET_ABI_VERSION 8
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -139,11 +139,19 @@ int yunet_pool_fwd(const float* z, const YunetBN* bn, float* out, int N, int H, 
  * bn->bstats.  accumulate != 0: dx += . */
 int yunet_pool_bwd(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
                    int accumulate, int N, int H, int W, int C, void* stream);
+/* The same with a second, full-size gradient of relu(bn(z)) added under the same mask: dx = mask (extra +
+ * route(dy_out)), one set of bn->bstats sums.  `extra` [N,H,W,C] fp32 (NULL = yunet_pool_bwd).  Used where a pyramid
+ * tap feeds both max_pool2d (yunet_backbone.py:39-40) and the identity branch of the TFPN merge (tfpn.py:39-40):
+ * autograd adds the two gradients of the tap; here yunet_upadd_bwd(dxa = NULL) leaves its share to this call (ABI 8). */
+int yunet_pool_bwd_add(const float* z, const YunetBN* bn, const float* dy_out, const float* extra, float* dx,
+                       int accumulate, int N, int H, int W, int C, void* stream);
 
 /* TFPN merge: out = relu(bn_a(za)) + nearest_up2(relu(bn_b(zb)))  (tfpn.py:39-40).
  * za [N,H,W,C], zb [N,H/2,W/2,C]. */
 int yunet_upadd_fwd(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
                     float* out, int N, int H, int W, int C, void* stream);
+/* dxa == NULL: the share of the fine tensor (mask_a dout, and bna->bstats) is NOT produced -- the caller hands `dout`
+ * to yunet_pool_bwd_add as `extra`; za is then not read. */
 int yunet_upadd_bwd(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
                     const float* dout, float* dxa, int accumulate_a, float* dxb,
                     int accumulate_b, int N, int H, int W, int C, void* stream);
@@ -333,6 +341,8 @@ int yunet_pool_fwd_bf16(const float* z, const YunetBN* bn, float* out, int N, in
                         void* stream);
 int yunet_pool_bwd_bf16(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
                         int accumulate, int N, int H, int W, int C, void* stream);
+int yunet_pool_bwd_add_bf16(const float* z, const YunetBN* bn, const float* dy_out, const float* extra, float* dx,
+                            int accumulate, int N, int H, int W, int C, void* stream);
 int yunet_upadd_fwd_bf16(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,
                          float* out, int N, int H, int W, int C, void* stream);
 int yunet_upadd_bwd_bf16(const float* za, const YunetBN* bna, const float* zb, const YunetBN* bnb,

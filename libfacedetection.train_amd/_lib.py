@@ -94,6 +94,8 @@ _SIGNATURES = {
     'yunet_dp_pool_fusion_ok': (C.c_int, [C.c_int] * 5),
     'yunet_pool_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p] +
                        [C.c_int] * 5 + [C.c_void_p]),
+    'yunet_pool_bwd_add': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.c_void_p, C.c_void_p] +
+                           [C.c_int] * 5 + [C.c_void_p]),
     'yunet_upadd_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.POINTER(YunetBN),
                                   C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     'yunet_upadd_bwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p, C.POINTER(YunetBN),
@@ -141,7 +143,7 @@ _SIGNATURES = {
     'yunet_comm_status': (C.c_int, [C.POINTER(YunetComm)]),
 }
 for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
-           'yunet_upadd_fwd', 'yunet_upadd_bwd'):
+           'yunet_pool_bwd_add', 'yunet_upadd_fwd', 'yunet_upadd_bwd'):
     _SIGNATURES[_n + '_bf16'] = _SIGNATURES[_n]      # same arguments, bf16 activation storage
 
 EXPORTED = sorted(_SIGNATURES)
@@ -168,7 +170,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 7:
+    if lib.yunet_abi_version() != 8:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -231,8 +231,10 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
                                     o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_POOL_BWD:
-                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_bwd_bf16 : yunet_pool_bwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1],
-                                    (float*)o.p[2], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                // p[3]: the upsample-add's share of the same gradient (NULL: plain max_pool2d backward)
+                rc = (o.i[11] == YUNET_BF16 ? yunet_pool_bwd_add_bf16 : yunet_pool_bwd_add)(
+                    (const float*)o.p[0], &o.bn[0], (const float*)o.p[1], (const float*)o.p[3], (float*)o.p[2], o.i[4], o.i[0],
+                    o.i[1], o.i[2], o.i[3], stream);
                 break;
             case YUNET_OP_UPADD_FWD:
                 rc = (o.i[11] == YUNET_BF16 ? yunet_upadd_fwd_bf16 : yunet_upadd_fwd)((const float*)o.p[0], &o.bn[0], (const float*)o.p[1], &o.bn[1],

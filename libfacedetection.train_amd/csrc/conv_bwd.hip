@@ -1899,8 +1899,13 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------- pool / upsample-add
+// `extra` (may be null): a second, FULL-SIZE gradient of the same activation y = relu(bn(z)) -- the share the
+// upsample-add of the neck sends to a pyramid tap (dsum, identity branch).  Both shares pass the same ReLU mask and
+// feed the same BatchNorm-backward sums, so dx = mask (extra + route(dy_out)) is written once here instead of
+// upadd_bwd writing mask extra and this kernel re-reading z and read-modify-writing dx (engine.py: _upadd / _pool).
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const act_t* __restrict__ z, YunetBN bn,
                                                        const float* __restrict__ dyo,
+                                                       const float* __restrict__ extra,
                                                        float* __restrict__ dx, int accumulate, int N,
                                                        int H, int W, int C) {
     const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
@@ -1943,6 +1948,22 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const act_t* __restrict__
             if (m > 0.0f) {
                 bst[i] += (double)gv[i];
                 bst[4 + i] += (double)(gv[i] * (bn_center(zv[am][i], k[i].mean, k[i].mean_lo) * k[i].invstd));
+            }
+        }
+        if (extra) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 e4 = *reinterpret_cast<const float4*>(
+                    extra + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + c4 * 4);
+                const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (yv[j][i] > 0.0f) {
+                        o[j][i] += ev[i];
+                        bst[i] += (double)ev[i];
+                        bst[4 + i] += (double)(ev[i] * (bn_center(zv[j][i], k[i].mean, k[i].mean_lo) * k[i].invstd));
+                    }
+                }
             }
         }
 #pragma unroll
@@ -2001,6 +2022,10 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
         for (int j = 0; j < 4; ++j) {
             const size_t off = (((size_t)n * H + 2 * by + (j >> 1)) * W + 2 * bx + (j & 1)) * C + c4 * 4;
             const float4 g4 = *reinterpret_cast<const float4*>(dout + off);
+            if (!dxa) {          // the fine tensor's share is applied by pool_bwd_kernel (extra): za is not read
+                sum[0] += g4.x; sum[1] += g4.y; sum[2] += g4.z; sum[3] += g4.w;
+                continue;
+            }
             const float4 z4 = act_ld4(za + off);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
             float o[4];
@@ -2055,7 +2080,7 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
         for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];          \
         atomic_add_f64(bn_slot(DST, SLOTS, C) + which * C + c, v);                   \
     }
-    UPADD_FLUSH(bsa, bna.bstats, bna.slots)
+    UPADD_FLUSH(bsa, (dxa ? bna.bstats : nullptr), bna.slots)
     UPADD_FLUSH(bsb, bnb.bstats, bnb.slots)
 #undef UPADD_FLUSH
 }
@@ -2254,13 +2279,18 @@ extern "C" int yunet_stem_bwd_rz(const float* img, const float* w, const float* 
 }
 #endif
 
-extern "C" int ACT_SUFFIX(yunet_pool_bwd)(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
-                                          int accumulate, int N, int H, int W, int C, void* stream) {
+extern "C" int ACT_SUFFIX(yunet_pool_bwd_add)(const float* z, const YunetBN* bn, const float* dy_out, const float* extra,
+                                              float* dx, int accumulate, int N, int H, int W, int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const act_t*>(z), *bn, dy_out, dx, accumulate, N, H, W, C);
+                       reinterpret_cast<const act_t*>(z), *bn, dy_out, extra, dx, accumulate, N, H, W, C);
     return hip_status();
+}
+
+extern "C" int ACT_SUFFIX(yunet_pool_bwd)(const float* z, const YunetBN* bn, const float* dy_out, float* dx,
+                                          int accumulate, int N, int H, int W, int C, void* stream) {
+    return ACT_SUFFIX(yunet_pool_bwd_add)(z, bn, dy_out, nullptr, dx, accumulate, N, H, W, C, stream);
 }
 
 extern "C" int ACT_SUFFIX(yunet_upadd_bwd)(const float* za, const YunetBN* bna, const float* zb,

@@ -202,6 +202,9 @@ class _T:
         self.grad_written = False
         self.bn_count = n * h * w   # elements per channel behind the BN statistics of `bn`
         self.pooled_into = None     # (pooled tensor, window-position bytes) when max_pool2d is this tensor's only consumer
+        self.plain_pool = False     # a pool_bwd op of its own will write this tensor's gradient (_pool, unfused form)
+        self.fuse_upadd = False     # ... and applies the TFPN merge's share of it too (_upadd: `upadd_share` = that gradient)
+        self.upadd_share = None
 
 
 class _BNRef:
@@ -668,10 +671,18 @@ class Plan:
                       i=[x.n, x.h, x.w, x.c])
         op.bn[0] = self._bn_struct(x.bn, cnt)
         self.fwd_a.append(op)
+        x.plain_pool = True
 
         def bwd():
+            # a pyramid tap: its other consumer is the identity branch of the TFPN merge, whose backward ran earlier (the
+            # merge comes later in the forward) and left its share of the gradient to this op -- same ReLU mask, same
+            # BatchNorm sums, so the tap's gradient is written ONCE instead of written, re-read and re-written
+            extra = None
+            if x.fuse_upadd:
+                assert x.upadd_share is not None, 'the merge backward must precede the pool backward of its tap'
+                extra = x.upadd_share.data_ptr()
             gx, acc = self._grad_of(x)
-            op = self._op(L.OP_POOL_BWD, p=[x.buf.data_ptr(), out.grad.data_ptr(), gx.data_ptr()],
+            op = self._op(L.OP_POOL_BWD, p=[x.buf.data_ptr(), out.grad.data_ptr(), gx.data_ptr(), extra],
                           i=[x.n, x.h, x.w, x.c, acc])
             op.bn[0] = self._bn_struct(x.bn, cnt)
             self.bwd.append(op)
@@ -686,13 +697,21 @@ class Plan:
         op.bn[0] = self._bn_struct(a.bn, a.n * a.h * a.w)
         op.bn[1] = self._bn_struct(b.bn, b.n * b.h * b.w)
         self.fwd_a.append(op)
+        # `a` is also max-pooled by a kernel of its own (built earlier in the forward = run later in the backward):
+        # leave a's share of the gradient to that kernel (see _pool)
+        a.fuse_upadd = a.plain_pool and not os.environ.get('YUNET_NO_UPADD_POOL_FUSION')
 
         def bwd():
-            ga, acc_a = self._grad_of(a)
+            if a.fuse_upadd:
+                a.upadd_share = out.grad
+                ga_ptr, acc_a = None, 0
+            else:
+                ga, acc_a = self._grad_of(a)
+                ga_ptr = ga.data_ptr()
             gb, acc_b = self._grad_of(b)
             op = self._op(L.OP_UPADD_BWD,
                           p=[a.buf.data_ptr(), b.buf.data_ptr(), out.grad.data_ptr(),
-                             ga.data_ptr(), gb.data_ptr()],
+                             ga_ptr, gb.data_ptr()],
                           i=[a.n, a.h, a.w, a.c, acc_a, acc_b])
             op.bn[0] = self._bn_struct(a.bn, a.n * a.h * a.w)
             op.bn[1] = self._bn_struct(b.bn, b.n * b.h * b.w)

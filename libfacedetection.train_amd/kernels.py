@@ -223,13 +223,16 @@ def pool_fwd(z, bn):
     return out
 
 
-def pool_bwd(z, bn, dy_out, dx=None, accumulate=False):
+def pool_bwd(z, bn, dy_out, dx=None, accumulate=False, extra=None):
+    """max_pool2d backward through relu(bn(z)); `extra`: a full-size gradient of the same activation added under the
+    same mask (yunet_pool_bwd_add: the TFPN merge's share of a pyramid tap)."""
     n, h, w, c = z.shape
     if dx is None:
         dx = torch.empty(z.shape, device=z.device, dtype=torch.float32)
     bnc = bn.c()
-    L.check(getattr(L.load(), 'yunet_pool_bwd' + _act(z)[1])(_p(z), C.byref(bnc), _p(dy_out), _p(dx), int(accumulate),
-                                                             n, h, w, c, _stream()), 'yunet_pool_bwd')
+    L.check(getattr(L.load(), 'yunet_pool_bwd_add' + _act(z)[1])(
+        _p(z), C.byref(bnc), _p(dy_out), _p(extra) if extra is not None else None, _p(dx), int(accumulate),
+        n, h, w, c, _stream()), 'yunet_pool_bwd_add')
     return dx
 
 
@@ -242,15 +245,17 @@ def upadd_fwd(za, bna, zb, bnb):
     return out
 
 
-def upadd_bwd(za, bna, zb, bnb, dout, dxa=None, acc_a=False, dxb=None, acc_b=False):
+def upadd_bwd(za, bna, zb, bnb, dout, dxa=None, acc_a=False, dxb=None, acc_b=False, skip_a=False):
+    """skip_a: the fine tensor's share is left to pool_bwd(extra=dout) -- returns (None, dxb)."""
     n, h, w, c = za.shape
-    dxa = torch.empty(za.shape, device=za.device, dtype=torch.float32) if dxa is None else dxa
+    if not skip_a:
+        dxa = torch.empty(za.shape, device=za.device, dtype=torch.float32) if dxa is None else dxa
     dxb = torch.empty(zb.shape, device=zb.device, dtype=torch.float32) if dxb is None else dxb
     a, b = bna.c(), bnb.c()
     L.check(getattr(L.load(), 'yunet_upadd_bwd' + _act(za)[1])(_p(za), C.byref(a), _p(zb), C.byref(b), _p(dout),
-                                                               _p(dxa), int(acc_a), _p(dxb), int(acc_b), n, h, w, c,
-                                                               _stream()), 'yunet_upadd_bwd')
-    return dxa, dxb
+                                                               None if skip_a else _p(dxa), int(acc_a), _p(dxb),
+                                                               int(acc_b), n, h, w, c, _stream()), 'yunet_upadd_bwd')
+    return (None if skip_a else dxa), dxb
 
 
 def bn_update_running(stats, running_mean, running_var, count, momentum=0.1):

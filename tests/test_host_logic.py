@@ -84,11 +84,16 @@ def test_flat_layout_is_a_bijection():
         assert lay.entries['bbox_head.multi_level_kps.0.conv1.weight'][0] == off0 + 6 * 64
 
 
-def test_plan_builds_on_cpu_and_orders_accumulation():
-    """Op lists can be built without a GPU (pointers only).  Taps consumed twice (pool + TFPN)
-    must have exactly one overwriting and one accumulating backward writer."""
+@pytest.mark.parametrize('fuse_taps', [True, False])
+def test_plan_builds_on_cpu_and_orders_accumulation(monkeypatch, fuse_taps):
+    """Op lists can be built without a GPU (pointers only).  Gradients with two backward writers (the lateral
+    outputs: head chain + TFPN merge; unfused form: also the taps, pool + TFPN) must have exactly one overwriting and
+    one accumulating writer.  Default form: a tap's gradient has ONE writer -- the pool backward, which takes the
+    merge's share as `extra` (p[3]) from a merge backward that ran before it with dxa = NULL."""
     import yunet_amd._lib as L
     import yunet_amd.engine as E
+    if not fuse_taps:
+        monkeypatch.setenv('YUNET_NO_UPADD_POOL_FUSION', '1')
     for kind, h in (('n', 320), ('s', 160)):
         eng = E.YuNetEngine(O.yunet_arch(kind), 'cpu')
         eng.use_lanes = True            # executor lanes for the head chains (off by default: no measured gain)
@@ -113,10 +118,25 @@ def test_plan_builds_on_cpu_and_orders_accumulation():
             elif op.opcode == L.OP_POOL_BWD:
                 writers.setdefault(op.p[2], []).append(op.i[4])
             elif op.opcode == L.OP_UPADD_BWD:
-                writers.setdefault(op.p[3], []).append(op.i[4])
+                if op.p[3]:
+                    writers.setdefault(op.p[3], []).append(op.i[4])
                 writers.setdefault(op.p[4], []).append(op.i[5])
         multi = [w for w in writers.values() if len(w) > 1]
-        assert len(multi) == 4                      # two backbone taps + two lateral outputs
+        assert len(multi) == (2 if fuse_taps else 4)        # two lateral outputs (+ two backbone taps)
+        pools = [op for op in plan.bwd if op.opcode == L.OP_POOL_BWD]
+        merges = [op for op in plan.bwd if op.opcode == L.OP_UPADD_BWD]
+        assert len(pools) == 2 and len(merges) == 2
+        if fuse_taps:
+            # each merge hands its gradient (p[2] = dout) to the pool backward of the same tap (p[0] = z), later in the list
+            for m in merges:
+                assert not m.p[3]
+                match = [q for q in pools if q.p[0] == m.p[0]]
+                assert len(match) == 1 and match[0].p[3] == m.p[2] and match[0].i[4] == 0
+                ops_b = list(plan.bwd)
+                assert [o.p[0] == m.p[0] and o.opcode == L.OP_UPADD_BWD for o in ops_b].index(True) < \
+                    [o.p[0] == m.p[0] and o.opcode == L.OP_POOL_BWD for o in ops_b].index(True)
+        else:
+            assert all(not q.p[3] for q in pools) and all(m.p[3] for m in merges)
         for w in writers.values():
             assert w[0] == 0 and all(a == 1 for a in w[1:])
         # executor lanes: the head chains of levels 1 and 2 run on side streams.  Every list forks a lane before

@@ -377,6 +377,62 @@ def test_upadd_fwd_bwd():
     assert rel_err(bnb.bstats, torch.cat([yb.grad.sum(dim=(0, 2, 3)), (yb.grad * xhb).sum(dim=(0, 2, 3))])) < 5e-5
 
 
+@pytest.mark.parametrize('n,h,w,c', [(2, 12, 20, 64), (3, 40, 40, 64)])
+def test_tap_gradient_written_once(n, h, w, c):
+    """A pyramid tap y = relu(bn(z)) feeds max_pool2d (yunet_backbone.py:39-40) AND the identity branch of the TFPN
+    merge (tfpn.py:39-40); autograd adds the two gradients.  upadd_bwd(skip_a) + pool_bwd(extra = the merge's gradient)
+    write the tap's gradient once: against fp64 autograd through both consumers, and against the unfused kernel pair
+    (dx identical bit for bit -- per element the same single addition -- the BatchNorm sums to fp64 rounding)."""
+    k = K()
+    g = torch.Generator().manual_seed(h + c)
+    za = (torch.randn(n, c, h, w, generator=g) * 2).double()
+    zb_ = (torch.randn(n, c, h // 2, w // 2, generator=g) * 2).double()
+    ga, ba = (torch.rand(c, generator=g) + 0.5).double(), torch.randn(c, generator=g).double() * .3
+    gb, bb = (torch.rand(c, generator=g) + 0.5).double(), torch.randn(c, generator=g).double() * .3
+    ga[3] = -ga[3]
+    ya, xha = bn_ref(za, ga, ba)
+    yb, xhb = bn_ref(zb_, gb, bb)
+    ya = ya.detach().requires_grad_(True)
+    yb = yb.detach().requires_grad_(True)
+    merged = F.relu(ya) + F.interpolate(F.relu(yb), scale_factor=2., mode='nearest')
+    pooled = F.max_pool2d(F.relu(ya), 2)
+    r_m = torch.randn(merged.shape, generator=g).double()
+    r_p = torch.randn(pooled.shape, generator=g).double()
+    ((merged * r_m).sum() + (pooled * r_p).sum()).backward()
+    zag, zbg = nhwc(za.float()).to(DEV), nhwc(zb_.float()).to(DEV)
+    dm, dp = nhwc(r_m.float()).to(DEV), nhwc(r_p.float()).to(DEV)
+
+    def bns():
+        return (k.BN(stats_of(zag), ga.float().to(DEV), ba.float().to(DEV), n * h * w,
+                     bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV)),
+                k.BN(stats_of(zbg), gb.float().to(DEV), bb.float().to(DEV), n * h * w // 4,
+                     bstats=torch.zeros(2 * c, dtype=torch.float64, device=DEV)))
+    # the unfused pair: the merge writes its share, the pool kernel re-reads z and accumulates
+    bna0, bnb0 = bns()
+    dxa0, dxb0 = k.upadd_bwd(zag, bna0, zbg, bnb0, dm)
+    k.pool_bwd(zag, bna0, dp, dx=dxa0, accumulate=True)
+    # the fused pair
+    bna1, bnb1 = bns()
+    none_a, dxb1 = k.upadd_bwd(zag, bna1, zbg, bnb1, dm, skip_a=True)
+    assert none_a is None
+    torch.cuda.synchronize()
+    assert float(bna1.bstats.abs().max()) == 0.0          # the merge left the tap's sums alone
+    dxa1 = torch.full(zag.shape, float('nan'), device=DEV)
+    k.pool_bwd(zag, bna1, dp, dx=dxa1, extra=dm)
+    torch.cuda.synchronize()
+    assert torch.equal(dxa1, dxa0) and torch.equal(dxb1, dxb0)
+    assert rel_err(bna1.bstats, bna0.bstats) < 1e-12 and torch.equal(bnb1.bstats, bnb0.bstats)
+    assert rel_err(nchw(dxa1.cpu()), ya.grad) < 2e-5
+    assert rel_err(nchw(dxb1.cpu()), yb.grad) < 2e-5
+    assert rel_err(bna1.bstats, torch.cat([ya.grad.sum(dim=(0, 2, 3)), (ya.grad * xha).sum(dim=(0, 2, 3))])) < 5e-5
+    # accumulate on top of an existing gradient (a third consumer that ran first)
+    base = torch.randn(zag.shape, device=DEV)
+    dxa2 = base.clone()
+    k.pool_bwd(zag, bna1, dp, dx=dxa2, accumulate=True, extra=dm)
+    torch.cuda.synchronize()
+    assert torch.equal(dxa2, base + dxa1)
+
+
 def _replicas(v, slots, g):
     """[2C] sums -> [slots, 2C] replica blocks that add up to v (unequal shares, one of them negative)."""
     wts = torch.rand(slots, 1, generator=g, dtype=torch.float64) + 0.1
