@@ -2095,8 +2095,33 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ bstats, float* _
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
 }
 
+// One row slice of a column: rows sl, sl + 16, ... added IN THAT ORDER.  Sixteen (then four) loads are issued before the
+// first addition: written as `v += p[...]` in a plain loop the compiler waits out every load before the next one is issued
+// (s_waitcnt vmcnt(0) per iteration), and a 768-row job -- 48 rows per slice, each an L2 / HBM round trip -- took 40 us
+// at the END of the backward, where nothing overlaps it.  Same additions in the same order: bit-identical sums.
+__device__ __forceinline__ float column_slice_sum(const float* __restrict__ p, int blocks, int width, int sl) {
+    float v = 0.0f;
+    int b = sl;
+    for (; b + 16 * 15 < blocks; b += 16 * 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = p[(size_t)(b + 16 * u) * width];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += x[u];
+    }
+    for (; b + 16 * 3 < blocks; b += 16 * 4) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = p[(size_t)(b + 16 * u) * width];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += x[u];
+    }
+    for (; b < blocks; b += 16) v += p[(size_t)b * width];
+    return v;
+}
+
 // out[j] (+)= sum_b partials[b][j]: 64 columns x 16 row-slices per workgroup (coalesced 256-byte
-// row segments, 16 loads in flight per column), combined in a fixed order -> deterministic.
+// row segments, 16 x 16 loads in flight per column), combined in a fixed order -> deterministic.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials,
                                                                int blocks, int width,
                                                                float* __restrict__ out,
@@ -2105,8 +2130,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     float v = 0.0f;
-    if (col < width)
-        for (int b = sl; b < blocks; b += 16) v += partials[(size_t)b * width + col];
+    if (col < width) v = column_slice_sum(partials + col, blocks, width, sl);
     s[sl][lane] = v;
     __syncthreads();
     if (sl == 0 && col < width) {
@@ -2121,14 +2145,19 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const YunetReduceJob* __restrict__ jobs,
                                                                      int njobs) {
     __shared__ float s[16][64];
-    int j = 0;
-    while (j + 1 < njobs && jobs[j + 1].chunk0 <= (int)blockIdx.x) ++j;
-    const YunetReduceJob job = jobs[j];
+    // the last job whose first chunk is <= this workgroup (chunk0 ascends): bisection -- 6 dependent scalar loads
+    // instead of up to njobs
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].chunk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const YunetReduceJob job = jobs[lo];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int col = ((int)blockIdx.x - job.chunk0) * 64 + lane;
     float v = 0.0f;
-    if (col < job.width)
-        for (int b = sl; b < job.blocks; b += 16) v += job.partials[(size_t)b * job.width + col];
+    if (col < job.width) v = column_slice_sum(job.partials + col, job.blocks, job.width, sl);
     s[sl][lane] = v;
     __syncthreads();
     if (sl == 0 && col < job.width) {

@@ -612,7 +612,19 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partials, int blo
     __shared__ float s_l[4];
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double v = 0.0;
-    for (int b = lane; b < blocks; b += 64) v += (double)partials[b * 4 + k];
+    {
+        // eight loads in flight, added in row order (a plain `v += p[...]` loop waits out every load before the next
+        // is issued: up to 32 round trips per lane between the loss kernel and the first backward kernel)
+        int b = lane;
+        for (; b + 64 * 7 < blocks; b += 64 * 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = partials[(b + 64 * u) * 4 + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (double)x[u];
+        }
+        for (; b < blocks; b += 64) v += (double)partials[b * 4 + k];
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     // deferred normaliser (yunet_loss with cfg.defer_num_total): cls, bbox and obj arrive un-normalised
