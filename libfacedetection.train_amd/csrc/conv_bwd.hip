@@ -2002,11 +2002,11 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
     const long long total = (long long)N * Hb * Wb * C4;
     const int c4 = threadIdx.x % C4;
     __shared__ float s_ta[5 * 64], s_tb[5 * 64];
-    bn_table_fill(s_ta, bna, C, threadIdx.x);
+    if (dxa) bn_table_fill(s_ta, bna, C, threadIdx.x);          // (the fine tensor's BatchNorm is not needed without its share)
     bn_table_fill(s_tb, bnb, C, threadIdx.x);
     __syncthreads();
     BNCoef ka[4], kb[4];
-    bn_table_get(s_ta, C, c4 * 4, ka);
+    bn_table_get(dxa ? s_ta : s_tb, C, c4 * 4, ka);
     bn_table_get(s_tb, C, c4 * 4, kb);
     double bsa[8], bsb[8];
 #pragma unroll
