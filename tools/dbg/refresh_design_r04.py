@@ -1,0 +1,63 @@
+# regenerate the "final build" block of DESIGN.md section 7 (round 4) from profiles/r04_*
+import json, re
+root='/root/repo/'
+b=json.load(open(root+'profiles/r04_bench.json'))
+s=open(root+'DESIGN.md').read()
+i0=s.index('`bench.py` of the final build (')
+i1=s.index('### Round 3 (one MI355X, `profiles/r03_*`')
+oc=b['other_configs']
+def g(key):
+    for k,v in oc.items():
+        if key in k: return v
+def num(x): return f"{x:,.0f}".replace(',', ' ')
+cpu=b['cpu_baseline']; r=b['roofline']; bs=r['by_shape']
+rows=['| kernel | launches/step | ms/step | algorithmic GB/s |','|---|---|---|---|']
+tot=0
+for k,v in b['kernels'].items():
+    tot+=v['ms']
+    if v['ms']>=0.04: rows.append("| `%s` | %d | %.3f | %.0f |" % (k, v['launches'], v['ms'], v['GBs']))
+rest=sum(v['ms'] for v in b['kernels'].values() if v['ms']<0.04)
+rows.append("| the rest (loss finalisation, BN tables, SGD, memset) | -- | %.3f | -- |" % rest)
+rows.append("| sum | %d | %.3f | |" % (sum(v['launches'] for v in b['kernels'].values()), tot))
+shape_txt = ', '.join('%s: %d x %.0f us = %.3f of the HBM peak' % (k, v['launches'], v['avg_launch_ms'] * 1000, v['frac']) for k, v in bs.items())
+t=json.load(open(root+'profiles/r04_pmc_traffic.json'))['kernels']
+alg={'dp_bwd16s_kernel<true>': 256*25600*(2*16*4)+256*6400*16*5, 'dp_bwd16s_kernel<false>': 256*6400*(3*16*4),
+     'stem_mma_kernel<false>': 256*(3*320*320*4+160*160*16*4), 'stem_mma_kernel<true>': 256*(3*320*320*4+160*160*16*4),
+     'dp_fwd16s_kernel<16,true>': 256*25600*(32*4)+256*6400*16*5, 'dp_fwd16s_kernel<16,false>': 256*6400*32*4, 'dp_fwd16s_kernel<64,false>': 256*6400*80*4,
+     'dp_fwd64s_kernel<true>': 256*6400*128*4+256*1600*64*5, 'dp_bwd_kernel<16,64,8,16,false,0,false,true>': 256*6400*(32+64)*4,
+     'dp_bwd64_kernel<8,false,false>': 256*6400*192*4, 'dp_bwd64_kernel<4,false,false>': 256*1600*192*4}
+parts=[]
+for k,a in alg.items():
+    if k in t:
+        v=t[k]; parts.append("`%s` %.0f MB read + %.0f MB written = %.0f MB per launch (x%.2f of %.0f MB)" % (k, v['read_bytes']/1e6, v['write_bytes']/1e6, v['traffic_bytes']/1e6, v['traffic_bytes']/a, a/1e6))
+pt=open(root+'profiles/r04_pytest_gpu.log').read()
+m=re.search(r'(\d+) passed.*? in ([\d.]+)s', pt)
+pytest_txt="%s passed, 1 skipped (needs 2 GPUs) in %.0f s" % (m.group(1), float(m.group(2))) if m else 'see the log'
+clk=b.get('gpu_clock_mhz',{})
+blk=f"""`bench.py` of the final build (`profiles/r04_bench.json`, 30 steps after 10 warm-up; GPU clock {clk.get('before')} / {clk.get('after')} MHz before / after the window; the pool's boxes run this build between 4.7 and 5.0 ms): **{b['ms_per_step']:.3f} ms per step, {num(b['value'])} images/s**; with every backward GEMM on the exact fp32
+matrix instruction (`exact_fp32_bwd`): {b['exact_fp32_bwd']['ms_per_step']:.3f} ms / {num(b['exact_fp32_bwd']['value'])} images/s; `other_configs`: bf16 activations {g('bf16')['ms_per_step']:.3f} ms
+({num(g('bf16')['value'])} img/s), YuNet_n 640² bs 64 {g('640x640')['ms_per_step']:.3f} ms ({num(g('640x640')['value'])} img/s), YuNet_s 320² bs 512 {g('YuNet_s')['ms_per_step']:.3f} ms ({num(g('YuNet_s')['value'])} img/s);
+`cpu_baseline` (kind `reference`: the unmodified reference step under the mmcv stub, 16 threads of the GPU box's host, bs 16):
+{cpu['value']:.1f} images/s (the oracle port: {cpu['port']['value']:.1f}; the same eager ops on the GPU: {cpu['gpu_eager']['value']:.0f}).  Over the reference's op graph
+(66.93 MB per image) the step moves {num(r['step_reference_graph_GBs'])} GB/s = {r['step_reference_graph_GBs']/8000:.2f} of the 8 TB/s HBM peak (round 3: 3 204).
+
+Per-kernel time inside one step (events around single launches; `profiles/r04_kernel_stats.csv` is the `rocprofv3
+--kernel-trace --stats` summary of the same command):
+
+""" + '\n'.join(rows) + f"""
+
+Dominant kernel by total time: `{r['kernel']}` -- {r['launches_per_step']} launches per step ({shape_txt}), {r['algorithmic_bytes_per_launch']/1e6:.1f} MB algorithmic per launch on average / {r['avg_launch_ms']*1000:.1f} us = {r['achieved']:.0f} GB/s = **{r['frac']:.3f} of the HBM peak** as the average over its four map sizes (`roofline.frac`; the 80x80 and 40x40 launches, the round-3 dominant instance, are at {bs['80x80']['frac']:.2f} / {bs['40x40']['frac']:.2f}, 0.427 / 0.304 in round 3); PMC traffic {r['traffic']/1e6:.1f} MB per launch = x{r['traffic']/r['algorithmic_bytes_per_launch']:.3f} of algorithmic.  The name now also covers the eight 20x20 / 10x10 launches, which lowers the average and shortens the step.
+
+HBM traffic of the rebuilt kernels (PMC passes, `profiles/r04_pmc_traffic.json`; calibration copy ×1.000 / ×1.000):
+""" + '; '.join(parts) + f""".
+
+GPU test suite (`profiles/r04_pytest_gpu.log`): {pytest_txt} -- the four full-batch oracle steps are compared with committed
+fixtures (`oracle/make_golden_fullstep.py`, 5822ba9) instead of being evaluated on the GPU box's host: round 3 needed 7.5–15 min.
+One-shot all-reduce between two processes on one GPU (`profiles/r04_oneshot_probe.json`, back-to-back calls): 6.4 µs for 4 B,
+10.2 µs for 50 KB, 27.5 µs for the whole 303 KB gradient (kernel launch + stores + flag wait + reduction; no xGMI crossing here).
+
+
+"""
+s=s[:i0]+blk+s[i1:]
+open(root+'DESIGN.md','w').write(s)
+print('ok', b['ms_per_step'], b['value'])
