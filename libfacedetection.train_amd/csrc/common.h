@@ -239,6 +239,31 @@ struct YunetOptions {
 };
 YunetOptions& yunet_options();
 
+#ifdef __HIPCC__
+// Prologue copy of a weight table from global memory: thread `tid` takes elements tid, tid + NT, ...  ALL loads are issued
+// before the first value is used.  Written as the obvious loop (`for (i = tid; i < COUNT; i += NT) lds[f(i)] = src[i]`)
+// the compiler waits out every load before it issues the next one (s_waitcnt vmcnt(0) in front of each LDS store): the
+// 64 x 64 pointwise weights of dp_fwd64s were 16 consecutive L2 / HBM round trips per workgroup, ~10 us in front of
+// every launch -- half the duration of the 10 x 10 launches.
+template <int COUNT, int NT, typename F>
+__device__ __forceinline__ void staged_table(const float* __restrict__ src, int tid, F&& put) {
+    constexpr int IT = (COUNT + NT - 1) / NT;
+    constexpr bool EXACT = COUNT % NT == 0;
+    float v[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = tid + k * NT;
+        v[k] = (EXACT || i < COUNT) ? src[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = tid + k * NT;
+        if (EXACT || i < COUNT) put(i, v[k]);
+    }
+}
+#endif
+
+
 // Small feature maps (the 20x20 / 10x10 pyramid levels) waste most of an 8x16 tile per image.
 // For them the tile grid is laid over a virtual CANVAS on which the images of the batch sit side
 // by side, R per row, one zero gap column / row between neighbours (pitch = size + 1): a tile then

@@ -339,14 +339,13 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             *reinterpret_cast<u32x4*>(s_w1tl + ci * G::WSTB + o0) = sp.lo;
         }
     } else {
-        for (int i = tid; i < COUT * CIN; i += BWD_THREADS) {
-            const float w = d.w_pw[i];
+        staged_table<COUT * CIN, BWD_THREADS>(d.w_pw, tid, [&](int i, float w) {       // (common.h: every load in flight first)
             s_w1[(i / CIN) * G::WS + (i % CIN)] = w;
             if (i % CIN == 0) s_w1[(i / CIN) * G::WS + CIN] = d.b_pw[i / CIN];   // bias rides in the row padding
             s_w1t[(i % CIN) * G::WST + (i / CIN)] = w;
-        }
+        });
     }
-    for (int i = tid; i < COUT * 9; i += BWD_THREADS) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
+    staged_table<COUT * 9, BWD_THREADS>(d.w_dw, tid, [&](int i, float w) { s_w2[(i % 9) * COUT + i / 9] = w; });
     for (int c = tid; c < COUT; c += BWD_THREADS) {
         // dz = k1 * (dy - c1 - xhat * c2) folded into dz = A dy + B z + D (see bn_fold in common.h)
         if (bn_out) {
@@ -1272,7 +1271,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
     }
     for (int c = tid; c < C; c += NT) s_b1[c] = d.b_pw[c];
-    for (int i = tid; i < C * 9; i += NT) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
+    staged_table<C * 9, NT>(d.w_dw, tid, [&](int i, float w) { s_w2[(i % 9) * C + i / 9] = w; });
     for (int c = tid; c < C; c += NT) {
         // dz = k1 * (dy - c1 - xhat * c2) folded into dz = A dy + B z + D (bn_fold in common.h): two FMAs and an
         // add per element instead of nine operations

@@ -291,22 +291,21 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
     constexpr int NCH = CIN / 8;                                      // 16-byte chunks per weight row
     __bf16* s_w1p = reinterpret_cast<__bf16*>(s_w1);                  // planes h | m | l, each [COUT][CIN], swizzled
     if constexpr (SPLIT3) {
-        for (int i = tid; i < COUT * CIN; i += 256) {
+        staged_table<COUT * CIN, 256>(d.w_pw, tid, [&](int i, float w) {       // (common.h: every load in flight first)
             const int co = i / CIN, ci = i % CIN;
-            const float w = d.w_pw[i];
             const __bf16 h = (__bf16)w;
             const float r1 = w - (float)h;
             const __bf16 m = (__bf16)r1;
             const __bf16 l = (__bf16)(r1 - (float)m);
             const int at = co * CIN + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
             s_w1p[at] = h; s_w1p[COUT * CIN + at] = m; s_w1p[2 * COUT * CIN + at] = l;
-        }
+        });
     } else if constexpr (BF16_MMA) {
-        for (int i = tid; i < COUT * CIN; i += 256) s_w1b[(i / CIN) * WSB + (i % CIN)] = (__bf16)d.w_pw[i];
+        staged_table<COUT * CIN, 256>(d.w_pw, tid, [&](int i, float w) { s_w1b[(i / CIN) * WSB + (i % CIN)] = (__bf16)w; });
     } else {
-        for (int i = tid; i < COUT * CIN; i += 256) s_w1[(i / CIN) * G::WS + (i % CIN)] = d.w_pw[i];
+        staged_table<COUT * CIN, 256>(d.w_pw, tid, [&](int i, float w) { s_w1[(i / CIN) * G::WS + (i % CIN)] = w; });
     }
-    for (int i = tid; i < COUT * 9; i += 256) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
+    staged_table<COUT * 9, 256>(d.w_dw, tid, [&](int i, float w) { s_w2[(i % 9) * COUT + i / 9] = w; });
     for (int i = tid; i < COUT; i += 256) s_b2[i] = d.b_dw[i];
     for (int c = tid; c < CIN; c += 256) {
         BNCoef k{0.f, 1.f, 0.f, 1.f};

@@ -54,7 +54,7 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
     const int H = d.H, W = d.W;
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
 
-    for (int i = tid; i < COUT * 9; i += NTHR) s_w2[(i % 9) * COUT + i / 9] = d.w_dw[i];
+    staged_table<COUT * 9, NTHR>(d.w_dw, tid, [&](int i, float w) { s_w2[(i % 9) * COUT + i / 9] = w; });
     for (int i = tid; i < COUT; i += NTHR) { s_b2[i] = d.b_dw[i]; s_b1[i] = d.b_pw[i]; }
     if (tid < CIN) {
         if (bn_in) {

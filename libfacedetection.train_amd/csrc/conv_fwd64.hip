@@ -84,9 +84,8 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
     const bool bn_in = d.in_transform == YUNET_T_BNRELU;
 
     // ---- prologue: tables ---------------------------------------------------------------------------------
-    for (int i = tid; i < C * C; i += NTHR) {
+    staged_table<C * C, NTHR>(d.w_pw, tid, [&](int i, float w) {
         const int co = i / C, ci = i % C;
-        const float w = d.w_pw[i];
         const __bf16 h = (__bf16)w;
         const int at = co * C + (((ci >> 3) ^ (co & (NCH - 1))) << 3) + (ci & 7);
         s_w1p[at] = h;
@@ -96,8 +95,8 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
         const __bf16 l = (__bf16)(r1 - (float)m);
         s_w1p[C * C + at] = m; s_w1p[2 * C * C + at] = l;
 #endif
-    }
-    for (int i = tid; i < C * 9; i += NTHR) s_w2[(i % 9) * C + i / 9] = d.w_dw[i];
+    });
+    staged_table<C * 9, NTHR>(d.w_dw, tid, [&](int i, float w) { s_w2[(i % 9) * C + i / 9] = w; });
     if (tid < C) {
         s_b2[tid] = d.b_dw[tid];
         s_b1[tid] = 0.0f;

@@ -35,7 +35,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_FETCH_SIZE.csv $OUT/${R}_pmc_WRITE_SIZE.csv $OUT/${R}_pmc_traffic.json
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/${R}_pmc_calib_FETCH_SIZE.csv $OUT/${R}_pmc_calib_WRITE_SIZE.csv $OUT/${R}_pmc_calib.json
+# QUICK=1: the bench line, the kernel statistics, the PMC traffic passes and the bf16 line only (steps 4 and 6 -- unit
+# utilisation and the torch-free kernel A/B -- keep their files from the previous full run)
 #   4. utilisation of the dominant kernels (derived metrics, one per pass): MFMA / VALU / LDS
+if [ -z "$QUICK" ]; then
 UT=""
 for c in MfmaUtil VALUBusy LdsUtil LDSBankConflict; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/util_${R}_$c -o p -- \
@@ -43,9 +46,11 @@ for c in MfmaUtil VALUBusy LdsUtil LDSBankConflict; do
   for f in $(find /tmp/util_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_util_$c.csv; UT="$UT $OUT/${R}_util_$c.csv"; done
 done
 python $GRAFT_REPO_ROOT/tools/pmc_mean.py $OUT/${R}_util.json $UT
+fi
 #   5. the second bench line (bf16 activations / bf16 forward matrix instruction, fp32 gradients)
 cd $GRAFT_REPO_ROOT
 timeout 300 python bench.py --dtype bf16 --steps 30 --warmup 10 --no-cpu-baseline --no-gpu-eager 2>/dev/null | tail -1 > $OUT/${R}_bench_bf16.json
+[ -n "$QUICK" ] && exit 0
 #   6. torch-free kernel A/B at sustained clocks (tools/ubench/bwd_ab), every variant a copy of THIS library (the
 #      environment switches are read once per library instance): the exact-fp32 matrix path (= the yardstick),
 #      dp_bwd64 with 8 waves / 8 x 16 tiles and with
