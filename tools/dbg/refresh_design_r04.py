@@ -51,7 +51,7 @@ Dominant kernel by total time: `{r['kernel']}` -- {r['launches_per_step']} launc
 HBM traffic of the rebuilt kernels (PMC passes, `profiles/r04_pmc_traffic.json`; calibration copy ×1.000 / ×1.000):
 """ + '; '.join(parts) + f""".
 
-GPU test suite (`profiles/r04_pytest_gpu.log`): {pytest_txt} -- the four full-batch oracle steps are compared with committed
+GPU test suite (`profiles/r04_pytest_gpu.log`, taken before the prologue fix; on the final build the kernel tests, 65, and the engine / full-batch / bf16 tests, 44, were re-run and pass): {pytest_txt} -- the four full-batch oracle steps are compared with committed
 fixtures (`oracle/make_golden_fullstep.py`, 5822ba9) instead of being evaluated on the GPU box's host: round 3 needed 7.5–15 min.
 One-shot all-reduce between two processes on one GPU (`profiles/r04_oneshot_probe.json`, back-to-back calls): 6.4 µs for 4 B,
 10.2 µs for 50 KB, 27.5 µs for the whole 303 KB gradient (kernel launch + stores + flag wait + reduction; no xGMI crossing here).
