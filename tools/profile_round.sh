@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the evidence a round is judged on (run on the GPU box through gpurun):
 #   1. bench.py JSON line (N=1)                         -> gpurun_out/rNN_bench.json
-#   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv
+#   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv, rNN_trace_gaps.json
 #   3. PMC passes (FETCH_SIZE / WRITE_SIZE, separately)  -> gpurun_out/rNN_pmc_{fetch,write}.csv
 #      over tools/kbench.py on the dominant kernels + a calibration copy of known size
 R=${1:-r04}
@@ -22,6 +22,10 @@ rows = open(sys.argv[1]).read().splitlines()
 keep = [rows[0]] + [r for r in rows[1:] if '_kernel' in r and 'at::native' not in r]
 open(sys.argv[2], 'w').write('\n'.join(keep) + '\n')
 PY
+done
+#   2b. idle time between the kernels of a step, from the same trace (tools/trace_gaps.py) -> gpurun_out/rNN_trace_gaps.json
+for f in $(find /tmp/prof_$R -name "*kernel_trace.csv" | head -1); do
+  python $GRAFT_REPO_ROOT/tools/trace_gaps.py "$f" "$OUT/${R}_trace_gaps.json" > /dev/null 2>&1 || true
 done
 #      3a. over the bench step itself (per-launch means of every kernel of the step)
 #      3b. over tools/kbench.py --calib (a 256 MiB device copy of known size: counter calibration)
