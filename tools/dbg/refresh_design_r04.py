@@ -1,6 +1,6 @@
 # regenerate the "final build" block of DESIGN.md section 7 (round 4) from profiles/r04_*
-import json, re
-root='/root/repo/'
+import json, os, re
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + '/'
 b=json.load(open(root+'profiles/r04_bench.json'))
 s=open(root+'DESIGN.md').read()
 i0=s.index('`bench.py` of the final build (')
