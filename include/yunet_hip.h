@@ -421,6 +421,7 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "fwd16s"             1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernels | 0: the tile kernels
  *   "stem_mma"           1 (default): the fp32 stem (yunet_stem_fwd; YUNET_OP_STEM_BWD with the stem's parameters in p[4],
  *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
+ *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 600 000; env YUNET_ONESHOT_TIMEOUT_MS)
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
 int yunet_set_option(const char* name, int value);
@@ -437,8 +438,10 @@ int yunet_set_option(const char* name, int value);
  * hipIpc* handles (one process per GPU).  Set-up, per rank: yunet_comm_alloc -> yunet_comm_export -> exchange the
  * 64-byte handles over any host channel -> yunet_comm_open on every peer's handle -> fill a YunetComm.
  * Every rank must issue the same sequence of yunet_allreduce calls on a given YunetComm (one YunetComm per stream
- * that carries collectives).  A peer that never arrives makes the wait give up after ~3 s: the buffer is left
- * untouched and yunet_comm_status() returns the sequence number of that call. */
+ * that carries collectives).  A peer that never arrives makes the wait give up after option "oneshot_timeout_ms"
+ * (default 600 000 = 10 min, the order of the process group's own time-out): yunet_comm_status() then returns the
+ * sequence number of that call and the buffer is POISONED with NaN (the shares of the blocks that gave up), so a
+ * caller that never reads the status word cannot train on un-reduced gradients unnoticed. */
 #define YUNET_MAX_RANKS 8
 #define YUNET_IPC_HANDLE_BYTES 64
 typedef struct YunetComm {

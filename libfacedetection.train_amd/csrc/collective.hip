@@ -20,13 +20,14 @@
 #include <string.h>
 
 #include "../../include/yunet_hip.h"
+#include "common.h"
 
 namespace {
 constexpr size_t FLAG_STRIDE = 128, FLAGS_BYTES = 2 * YUNET_MAX_RANKS * FLAG_STRIDE;
 constexpr size_t CTR_OFF = FLAGS_BYTES, SLOTS_OFF = 4096;
 constexpr int AR_THREADS = 512;
 typedef float vf4 __attribute__((ext_vector_type(4)));
-constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;      // wall_clock64: 100 MHz -> 3 s
+constexpr unsigned long long TICKS_PER_MS = 100000ull;           // wall_clock64: 100 MHz
 
 struct ARArgs {
     unsigned char* inbox[YUNET_MAX_RANKS];
@@ -34,6 +35,7 @@ struct ARArgs {
     float* buf;
     unsigned long long n;
     unsigned long long slot_bytes;
+    unsigned long long timeout_ticks;      // option "oneshot_timeout_ms" (default 10 min, like the process group's)
     unsigned seq;
     int rank, world;
     float scale;
@@ -79,14 +81,21 @@ __global__ __launch_bounds__(AR_THREADS) void oneshot_allreduce_kernel(const ARA
                 ok = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.inbox[a.rank] + CTR_OFF), __ATOMIC_ACQUIRE,
                                        __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)a.seq * (unsigned)a.world;
             if (!ok) {
-                if (wall_clock64() - t0 > TIMEOUT_TICKS) { s_fail = 1; break; }
+                if (wall_clock64() - t0 > a.timeout_ticks) { s_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
     }
     __syncthreads();
-    if (s_fail) {                    // a peer never arrived: leave buf alone, tell the host which call it was
+    if (s_fail) {
+        // A peer never arrived.  The failure must be LOUD: the host status word names the call (the engine reads it
+        // every step and raises), and this block's share of buf is poisoned with NaN so that a caller which never
+        // looks at the status still sees it in its loss / parameters instead of training on un-reduced gradients
+        // (a block that did see all flags reduces its share normally: the result is then partly reduced, partly NaN).
         if (tid == 0 && a.status) *reinterpret_cast<volatile int32_t*>(a.status) = (int32_t)a.seq;
+        const size_t share = ((n + (size_t)a.world * 4 - 1) / ((size_t)a.world * 4)) * 4;
+        const size_t lo = (size_t)p * share, hi = lo + share < n ? lo + share : n;
+        for (size_t i = lo + tid; i < hi; i += AR_THREADS) a.buf[i] = __builtin_nanf("");
         return;
     }
     __threadfence_system();
@@ -186,6 +195,10 @@ extern "C" int yunet_allreduce(YunetComm* c, float* buf, size_t n, int mean, voi
     a.buf = buf;
     a.n = n;
     a.slot_bytes = c->slot_bytes;
+    {
+        const int ms = yunet_options().oneshot_timeout_ms;
+        a.timeout_ticks = (unsigned long long)(ms > 0 ? ms : 600000) * TICKS_PER_MS;
+    }
     a.seq = ++c->seq;            // 1, 2, ...: the same on every rank as long as the ranks make the same calls
     a.rank = c->rank;
     a.world = c->world;

@@ -236,8 +236,49 @@ struct YunetOptions {
     int fwd16s;              // 1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernel (conv_fwd16.hip)
     int stem_mma;            // 1 (default): the fp32 stem forward / weight gradient on the matrix cores (conv_stem.hip; the
                              // backward recomputes z from the image); 0: the VALU tile kernels
+    int oneshot_timeout_ms;  // how long yunet_allreduce waits for a peer before it poisons the buffer and sets the status
+                             // word (default 600 000 = 10 min, the process group's order of magnitude; tests use 1 000)
 };
 YunetOptions& yunet_options();
+
+// ---- per-device launch set-up ------------------------------------------------------------------------------------
+// hipFuncSetAttribute (the raised dynamic-LDS limit) and the occupancy query are PER DEVICE, and executor lanes are per
+// (host thread, device): a process may drive several devices from several threads.  Launchers therefore keep what they
+// computed in one slot per device (process-wide statics left a second device without the raised limit).  A
+// slot holds 0 until its device has been set up; two threads racing on the same slot compute the same value.
+#include <atomic>
+constexpr int YUNET_MAX_DEVICES = 16;
+struct PerDevice {
+    std::atomic<int> v[YUNET_MAX_DEVICES];
+};
+inline int yunet_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= YUNET_MAX_DEVICES) return -1;
+    return dev;
+}
+// value cached for the current device; `compute` returns > 0, or <= 0 for failure (not cached, passed through)
+template <typename F>
+inline int per_device(PerDevice& slots, F&& compute) {
+    const int dev = yunet_device_index();
+    if (dev < 0) return compute();
+    int v = slots.v[dev].load(std::memory_order_acquire);
+    if (v == 0) {
+        v = compute();
+        if (v > 0) slots.v[dev].store(v, std::memory_order_release);
+    }
+    return v;
+}
+// compute units of the current device (256 on MI355X); the persistent grids are a multiple of it
+inline int yunet_cu_count() {
+    static PerDevice cus;
+    return per_device(cus, [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            return 256;
+        return n;
+    });
+}
 
 #ifdef __HIPCC__
 // Prologue copy of a weight table from global memory: thread `tid` takes elements tid, tid + NT, ...  ALL loads are issued

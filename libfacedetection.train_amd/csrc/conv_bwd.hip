@@ -964,12 +964,12 @@ int launch_dp_bwd(const YunetDP* d, hipStream_t stream) {
     if constexpr (FULL) {
         if (d->H % TH != 0 || d->W % TW != 0) return YUNET_EINVAL;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY, FULL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        attr_set = true;
-    }
+    static PerDevice attr_set;      // per device (common.h)
+    if (per_device(attr_set, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd_kernel<CIN, COUT, TH, TW, PACKED, GEMM, POOLDY, FULL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM) == hipSuccess ? 1 : -1;
+        }) < 0)
+        return YUNET_EINVAL;
     PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
     pk.on = PACKED ? 1 : 0;
     if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
@@ -1732,12 +1732,12 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 template <int NW, bool PACKED, bool POOLDY>
 int launch_dp_bwd64(const YunetDP* d, hipStream_t stream) {
     using G = bwd64::Geo<NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd64_kernel<NW, PACKED, POOLDY>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        attr_set = true;
-    }
+    static PerDevice attr_set;      // per device (common.h)
+    if (per_device(attr_set, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd64_kernel<NW, PACKED, POOLDY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM) == hipSuccess ? 1 : -1;
+        }) < 0)
+        return YUNET_EINVAL;
     PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
     pk.on = PACKED ? 1 : 0;
     if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;

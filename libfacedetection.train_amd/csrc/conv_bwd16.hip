@@ -452,13 +452,12 @@ int bwd16s_rows(int N, int H, int W, int waves) {
 template <bool POOLDY>
 int launch_bwd16s(const YunetDP* d, hipStream_t stream) {
     constexpr size_t smem = (size_t)b16s::SMEM_F * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd16s_kernel<POOLDY>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return YUNET_EINVAL;
-        attr_set = true;
-    }
+    static PerDevice attr_set;      // per device (common.h)
+    if (per_device(attr_set, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(dp_bwd16s_kernel<POOLDY>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess ? 1 : -1;
+        }) < 0)
+        return YUNET_EINVAL;
     if ((long long)d->H * d->W * 16 * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
     const int grid = d->wgrad_blocks;                                             // every workgroup writes its partial row
     const int R = bwd16s_rows(d->N, d->H, d->W, grid * b16s::WAVES);

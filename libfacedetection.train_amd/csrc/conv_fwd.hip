@@ -623,24 +623,26 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
 template <int CIN, int COUT, int TH, int TW, bool PACKED = false, bool POOL = false>
 int launch_dp_fwd(const YunetDP* d, hipStream_t stream) {
     using G = DpGeom<CIN, COUT, TH, TW>;
-    static int blocks_per_cu = 0;
-    if (!blocks_per_cu) {
+    static PerDevice per_cu;        // resident workgroups per CU, per device (common.h)
+    const int blocks_per_cu = per_device(per_cu, [] {
         const void* fn = reinterpret_cast<const void*>(dp_fwd_kernel<CIN, COUT, TH, TW, PACKED, POOL>);
-        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM) != hipSuccess) return -1;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, G::SMEM) != hipSuccess || nb < 1)
             nb = 1;
-        blocks_per_cu = nb > 4 ? 4 : nb;
+        nb = nb > 4 ? 4 : nb;
         const int forced = yunet_options().fwd_blocks_per_cu;       // occupancy experiments only
-        if (forced >= 1 && forced <= blocks_per_cu) blocks_per_cu = forced;
-    }
+        if (forced >= 1 && forced <= nb) nb = forced;
+        return nb;
+    });
+    if (blocks_per_cu < 1) return YUNET_EINVAL;
     // persistent grid: exactly the resident workgroups, so every one pipelines many tiles
     PackGeom pk = dp_pack_geom(d->N, d->H, d->W);
     pk.on = PACKED ? 1 : 0;
     if (!dp_pack_fits(pk, d->x_img_stride, d->z_img_stride)) return YUNET_EINVAL;
     const int tiles = PACKED ? ((pk.CW + TW - 1) / TW) * ((pk.CH + TH - 1) / TH)
                              : d->N * ((d->W + TW - 1) / TW) * ((d->H + TH - 1) / TH);
-    const int resident = 256 * blocks_per_cu;
+    const int resident = yunet_cu_count() * blocks_per_cu;
     const int grid = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL((dp_fwd_kernel<CIN, COUT, TH, TW, PACKED, POOL>), dim3(grid), dim3(256), G::SMEM, stream, *d, pk);
     return hip_status();

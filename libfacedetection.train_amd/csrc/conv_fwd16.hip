@@ -271,18 +271,19 @@ template <int COUT, bool POOL>
 int launch_fwd16s(const YunetDP* d, hipStream_t stream) {
     using GG = f16s::G<COUT>;
     constexpr size_t smem = ((size_t)f16s::WAVES * GG::WAVE_F + 11 * COUT + 3 * 16) * 4 + 2 * COUT * 8;
-    static int blocks_per_cu = 0;
-    const void* fn = reinterpret_cast<const void*>(dp_fwd16s_kernel<COUT, POOL>);
-    if (!blocks_per_cu) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return YUNET_EINVAL;
+    static PerDevice per_cu;        // resident workgroups per CU, per device (common.h)
+    const int blocks_per_cu = per_device(per_cu, [] {
+        const void* fn = reinterpret_cast<const void*>(dp_fwd16s_kernel<COUT, POOL>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, f16s::NTHR, smem) != hipSuccess || nb < 1) nb = 1;
-        blocks_per_cu = nb > 3 ? 3 : nb;
-    }
+        return nb > 3 ? 3 : nb;
+    });
+    if (blocks_per_cu < 1) return YUNET_EINVAL;
     if ((long long)d->H * d->W * COUT * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
     if (d->x_dtype != YUNET_ACT_DTYPE || d->z_dtype != YUNET_ACT_DTYPE) return YUNET_EINVAL;
     constexpr int HALO = POOL ? 2 : 1, OUTW = GG::PXW - 2 * HALO;
-    int grid = 256 * blocks_per_cu;
+    int grid = yunet_cu_count() * blocks_per_cu;
     const int R = fwd16s_rows(d->N, d->H, d->W, OUTW, grid * f16s::WAVES, POOL);
     const long long tasks = (long long)d->N * ((d->W + OUTW - 1) / OUTW) * ((d->H + R - 1) / R);
     const long long need = (tasks + f16s::WAVES - 1) / f16s::WAVES;

@@ -427,16 +427,17 @@ static int fwd64s_rows(int N, int H, int W, int waves) {
 
 template <bool POOL>
 static int launch_fwd64s(const YunetDP* d, hipStream_t stream) {
-    static int blocks_per_cu = 0;
-    const void* fn = reinterpret_cast<const void*>(dp_fwd64s_kernel<POOL>);
-    if (!blocks_per_cu) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f64s::SMEM) != hipSuccess) return YUNET_EINVAL;
+    static PerDevice per_cu;        // resident workgroups per CU, per device (common.h)
+    const int blocks_per_cu = per_device(per_cu, [] {
+        const void* fn = reinterpret_cast<const void*>(dp_fwd64s_kernel<POOL>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f64s::SMEM) != hipSuccess) return -1;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, f64s::NTHR, f64s::SMEM) != hipSuccess || nb < 1) nb = 1;
-        blocks_per_cu = nb > 3 ? 3 : nb;
-    }
+        return nb > 3 ? 3 : nb;
+    });
+    if (blocks_per_cu < 1) return YUNET_EINVAL;
     if ((long long)d->H * d->W * 64 * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
-    int grid = 256 * blocks_per_cu;
+    int grid = yunet_cu_count() * blocks_per_cu;
     int R = fwd64s_rows(d->N, d->H, d->W, grid * f64s::WAVES);
     if (POOL && (R & 1)) ++R;                                                      // bands hold whole row pairs
     const long long tasks = (long long)d->N * ((d->W + f64s::TW - 1) / f64s::TW) * ((d->H + R - 1) / R);

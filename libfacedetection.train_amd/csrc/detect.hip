@@ -239,12 +239,15 @@ extern "C" int yunet_detect(const float* flat, const YunetLevels* lv, int N, int
     while (padP < P) padP <<= 1;
     const int lds_keys = padP < DET_LDS_KEYS ? padP : DET_LDS_KEYS;
     const size_t smem = (size_t)lds_keys * 8 + (size_t)DET_BOX_CAP * 16;
-    static size_t attr = 0;
-    if (smem > attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    // the largest dynamic-LDS size is always the same (DET_LDS_KEYS keys + the box cache): raise the limit to it
+    // once per device (common.h: per_device) instead of tracking a growing process-wide maximum
+    static PerDevice attr_set;
+    constexpr size_t smem_max = (size_t)DET_LDS_KEYS * 8 + (size_t)DET_BOX_CAP * 16;
+    if (per_device(attr_set, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max) == hipSuccess ? 1 : -1;
+        }) < 0)
+        return YUNET_EINVAL;
     hipLaunchKernelGGL(detect_kernel<true>, dim3(N), dim3(DET_THREADS), smem, (hipStream_t)stream, flat,
                        (const float*)nullptr, (const int32_t*)nullptr, L, P, padP, lds_keys, score_thr, iou_thr,
                        max_out, dets, kps, (int32_t*)nullptr, count, (unsigned char*)scratch);
@@ -260,12 +263,15 @@ extern "C" int yunet_nms(const float* boxes, const float* scores, const int32_t*
     while (padP < K) padP <<= 1;
     const int lds_keys = padP < DET_LDS_KEYS ? padP : DET_LDS_KEYS;
     const size_t smem = (size_t)lds_keys * 8 + (size_t)DET_BOX_CAP * 16;
-    static size_t attr = 0;
-    if (smem > attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
+    // the largest dynamic-LDS size is always the same (DET_LDS_KEYS keys + the box cache): raise the limit to it
+    // once per device (common.h: per_device) instead of tracking a growing process-wide maximum
+    static PerDevice attr_set;
+    constexpr size_t smem_max = (size_t)DET_LDS_KEYS * 8 + (size_t)DET_BOX_CAP * 16;
+    if (per_device(attr_set, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(detect_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max) == hipSuccess ? 1 : -1;
+        }) < 0)
+        return YUNET_EINVAL;
     Levels L{};
     hipLaunchKernelGGL(detect_kernel<false>, dim3(N), dim3(DET_THREADS), smem, (hipStream_t)stream, boxes, scores,
                        counts, L, K, padP, lds_keys, score_thr, iou_thr, max_out, dets, (float*)nullptr, keep, count,

@@ -15,6 +15,7 @@ per input shape as an array of `YunetOp` and replayed by ONE C call per phase
 PyTorch supplies device memory, streams and torch.distributed only.
 """
 import collections
+import warnings
 import ctypes as C
 import math
 import os
@@ -842,6 +843,7 @@ class YuNetEngine:
             max_gt = max(int(cnt_t.max()), 1)
         else:
             max_gt = max([int(b.shape[0]) for b in gt_bboxes] + [1])
+        self._check_oneshot()
         plan = self.get_plan(n, h, w, max_gt)
         self.plan = plan
         self._img = img
@@ -933,6 +935,7 @@ class YuNetEngine:
         num_pos + bucket B + the wait for bucket A at the end of backward: the time the launch stream spends
         in or behind communication; bucket A itself runs under the backward kernels of the early stages."""
         torch.cuda.synchronize(self.device)
+        self._check_oneshot()
         tot = {}
         for name, e0, e1 in self._comm_events:
             tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
@@ -954,7 +957,16 @@ class YuNetEngine:
         an all-gather of the process group bit for bit; on a mismatch nothing changes and False is returned."""
         from .oneshot import OneShotAllReduce
         nbytes = self.params.grad_buf.numel() * 4
-        comms = [OneShotAllReduce(self.device, nbytes, self.process_group) for _ in range(2)]
+        comms = []
+        try:
+            for _ in range(2):
+                comms.append(OneShotAllReduce(self.device, nbytes, self.process_group))
+        except (RuntimeError, ValueError) as e:
+            # raised on EVERY rank together (oneshot.py: _agree; world > 8): all stay on the process group
+            warnings.warn(f'one-shot all-reduce unavailable, staying on the process group: {e}')
+            for c in comms:
+                c.close()
+            return False
         if verify and not all(c.verify() for c in comms):
             for c in comms:
                 c.close()
@@ -971,6 +983,19 @@ class YuNetEngine:
     def oneshot_status(self):
         """0, or the sequence number of the first message whose wait for a peer timed out (host read)."""
         return max((c.status() for c in (self._os_side, self._os_main) if c is not None), default=0)
+
+    def _check_oneshot(self):
+        """Called at the start of every step (and by comm_report): a host read of the communicators' status words,
+        no synchronisation.  A peer that did not arrive within `oneshot_timeout_ms` left this rank's buffer poisoned
+        with NaN (csrc/collective.hip); the ranks' parameters would diverge silently if training went on, and the
+        process group cannot repair a step that was already applied -- so this raises."""
+        if self._os_side is None and self._os_main is None:
+            return
+        st = self.oneshot_status()
+        if st:
+            raise RuntimeError(f'one-shot all-reduce: message {st} timed out waiting for a peer (option '
+                               f'oneshot_timeout_ms); the reduced buffer was poisoned with NaN.  A rank stalled or '
+                               f'died -- restart from the last checkpoint (YUNET_ONESHOT_AR=0 uses the process group)')
 
     def _allreduce_mean(self, t, comm=None):
         """Mean over ranks, in place, on the current stream.  RCCL averages inside the collective

@@ -27,39 +27,64 @@ class OneShotAllReduce:
             raise RuntimeError('OneShotAllReduce needs an initialised process group (handle exchange)')
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        if self.world > L.MAX_RANKS:
+        if self.world > L.MAX_RANKS:       # the same on every rank: raising here cannot strand a peer
             raise ValueError(f'one node only: world size {self.world} > {L.MAX_RANKS}')
         self.device = torch.device(device)
         self.lib = L.load()
         self._mapped = []
         self._inbox = self._status = None
-        with torch.cuda.device(self.device):
-            nbytes = self.lib.yunet_comm_inbox_bytes(self.world, int(max_bytes))
-            if nbytes == 0:
-                raise ValueError('bad world size / message size')
-            inbox, status = C.c_void_p(), C.c_void_p()
-            L.check(self.lib.yunet_comm_alloc(nbytes, C.byref(inbox), C.byref(status)), 'yunet_comm_alloc')
-            self._inbox, self._status = inbox.value, status.value
-            handle = C.create_string_buffer(L.IPC_HANDLE_BYTES)
-            L.check(self.lib.yunet_comm_export(self._inbox, handle), 'yunet_comm_export (hipIpcGetMemHandle)')
-            handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
-            comm = L.YunetComm()
-            comm.rank, comm.world, comm.seq = self.rank, self.world, 0
-            comm.slot_bytes = (nbytes - 4096) // (2 * self.world)
-            comm.status = self._status
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    comm.inbox[r] = self._inbox
-                    continue
-                mapped = C.c_void_p()
-                L.check(self.lib.yunet_comm_open(C.create_string_buffer(h, L.IPC_HANDLE_BYTES), C.byref(mapped)),
-                        f'yunet_comm_open (hipIpcOpenMemHandle, rank {r})')
-                self._mapped.append(mapped.value)
-                comm.inbox[r] = mapped.value
-            self.comm = comm
-            self.max_bytes = int(comm.slot_bytes)
-        dist.barrier(group=group)        # every inbox is mapped everywhere before the first message
+        # Set-up has two local steps that can fail on ONE rank only (allocation / export of the inbox; mapping the
+        # peers' handles: hipIpcOpenMemHandle denied in a container, a peer on another node).  A rank that raised
+        # there alone would leave its peers blocked in the next collective, so every rank first reports how its
+        # step went and all ranks raise TOGETHER; engine.enable_oneshot() turns that into "stay on the
+        # process group" on every rank.
+        err, handle_bytes, nbytes = None, None, 0
+        try:
+            with torch.cuda.device(self.device):
+                nbytes = self.lib.yunet_comm_inbox_bytes(self.world, int(max_bytes))
+                if nbytes == 0:
+                    raise ValueError('bad world size / message size')
+                inbox, status = C.c_void_p(), C.c_void_p()
+                L.check(self.lib.yunet_comm_alloc(nbytes, C.byref(inbox), C.byref(status)), 'yunet_comm_alloc')
+                self._inbox, self._status = inbox.value, status.value
+                handle = C.create_string_buffer(L.IPC_HANDLE_BYTES)
+                L.check(self.lib.yunet_comm_export(self._inbox, handle), 'yunet_comm_export (hipIpcGetMemHandle)')
+                handle_bytes = bytes(handle.raw)
+        except Exception as e:          # noqa: BLE001 -- reported to every rank below
+            err = f'rank {self.rank}: {e!r}'
+        reports = [None] * self.world
+        dist.all_gather_object(reports, (err, handle_bytes), group=group)
+        self._agree([r[0] for r in reports])
+        err = None
+        try:
+            with torch.cuda.device(self.device):
+                comm = L.YunetComm()
+                comm.rank, comm.world, comm.seq = self.rank, self.world, 0
+                comm.slot_bytes = (nbytes - 4096) // (2 * self.world)
+                comm.status = self._status
+                for r, (_, h) in enumerate(reports):
+                    if r == self.rank:
+                        comm.inbox[r] = self._inbox
+                        continue
+                    mapped = C.c_void_p()
+                    L.check(self.lib.yunet_comm_open(C.create_string_buffer(h, L.IPC_HANDLE_BYTES), C.byref(mapped)),
+                            f'yunet_comm_open (hipIpcOpenMemHandle, rank {r})')
+                    self._mapped.append(mapped.value)
+                    comm.inbox[r] = mapped.value
+                self.comm = comm
+                self.max_bytes = int(comm.slot_bytes)
+        except Exception as e:          # noqa: BLE001
+            err = f'rank {self.rank}: {e!r}'
+        opened = [None] * self.world
+        dist.all_gather_object(opened, err, group=group)    # also the barrier: every inbox is mapped everywhere
+        self._agree(opened)
+
+    def _agree(self, errors):
+        """All ranks hold the same list: raise on all of them if any rank failed its local step."""
+        bad = [e for e in errors if e]
+        if bad:
+            self.close()
+            raise RuntimeError('one-shot all-reduce set-up failed on ' + '; '.join(bad))
 
     def all_reduce_(self, t, mean=False, stream=None):
         """In place, on `stream` (default: the current stream): sum (mean: / world) over the ranks."""
@@ -91,8 +116,13 @@ class OneShotAllReduce:
         want = parts[0].clone()
         for p in parts[1:]:
             want += p
-        got = self.all_reduce_(x.clone())
-        torch.cuda.synchronize(self.device)
+        # a self-check must not sit out the production time-out (minutes) if a peer's stores never become visible
+        prev = L.set_option('oneshot_timeout_ms', 5000)
+        try:
+            got = self.all_reduce_(x.clone())
+            torch.cuda.synchronize(self.device)
+        finally:
+            L.set_option('oneshot_timeout_ms', prev)
         ok = self.status() == 0 and torch.equal(got, want)
         flag = torch.tensor([1 if ok else 0])
         if dist.get_backend(self.group) == 'nccl':

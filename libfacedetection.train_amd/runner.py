@@ -287,6 +287,11 @@ class EvalHook(Hook):
             dev = torch.device('cuda', torch.cuda.current_device())
         sharded = self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         if sharded:
+            # BatchNorm running statistics are per rank (no SyncBN, broadcast_buffers=False): the reference's
+            # DistEvalHook broadcasts rank 0's running_var / running_mean before multi_gpu_test
+            # (mmdet/core/evaluation/eval_hooks.py:101-107) so that every shard is evaluated by the SAME model --
+            # the one rank 0 checkpoints.  Here the buffers of all layers are two flat tensors.
+            broadcast_bn_buffers(target)
             dets = multi_gpu_test(target, self.dataset, dev, self.scale, self.max_images)      # None off rank 0
         else:
             dets = single_gpu_test(target, self.dataset, dev, self.scale, self.max_images) if runner.rank == 0 else None
@@ -300,6 +305,27 @@ class EvalHook(Hook):
                                                        ', '.join(f'{k}: {float(v):.4f}' for k, v in res.items())))
             if self.best is None or res.get('mAP', 0.0) > self.best:
                 self.best = res.get('mAP', 0.0)
+
+
+def broadcast_bn_buffers(model, src=0):
+    """dist.broadcast of every BatchNorm running_var / running_mean from rank `src` (DistEvalHook._do_evaluate,
+    mmdet/core/evaluation/eval_hooks.py:101-107).  Returns the number of tensors sent (0 without a process group)."""
+    if not (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        return 0
+    eng = getattr(model, 'engine', None)
+    if eng is not None:          # the fused path: all layers' buffers live in two flat device tensors
+        bufs = [eng.params.running_var, eng.params.running_mean]
+    else:                        # a model that has not been bound to a device yet: its module buffers
+        bufs = [b for n, b in model.named_buffers() if n.endswith('running_var') or n.endswith('running_mean')]
+    gloo = torch.distributed.get_backend() != 'nccl'
+    for b in bufs:
+        if gloo and b.is_cuda:   # CPU process group (tests, ranks sharing one GPU): through the host
+            h = b.detach().cpu()
+            torch.distributed.broadcast(h, src)
+            b.copy_(h)
+        else:
+            torch.distributed.broadcast(b, src)
+    return len(bufs)
 
 
 class LoggerHook(Hook):

@@ -11,9 +11,12 @@ HERE=$(cd "$(dirname "$0")" && pwd)
 SRC=${1:-${YUNET_REFERENCE_ROOT:-/root/reference}}
 DST=$HERE/_ref
 [ -d "$SRC/mmdet" ] || { echo "no reference tree at $SRC"; exit 0; }
-rm -rf "$DST"
-mkdir -p "$DST/configs"
-python3 - "$HERE" "$SRC" "$DST" <<'PY'
+# build into a scratch directory and swap it in only when complete: a failure half-way leaves the previous copy alone
+TMP=$HERE/_ref.tmp.$$
+rm -rf "$TMP"
+mkdir -p "$TMP/configs"
+trap 'rm -rf "$TMP"' EXIT
+python3 - "$HERE" "$SRC" "$TMP" <<'PY'
 import os, shutil, sys
 here, src, dst = sys.argv[1:4]
 sys.path.insert(0, here)
@@ -29,3 +32,6 @@ for cfg in ('yunet_n.py', 'yunet_s.py'):
     shutil.copyfile(os.path.join(src, 'configs', cfg), os.path.join(dst, 'configs', cfg))
 print(f'oracle/_ref: {n} reference modules + 2 configs from {src}')
 PY
+rm -rf "$DST"
+mv "$TMP" "$DST"
+trap - EXIT

@@ -150,3 +150,89 @@ def test_sharded_evaluation_restores_dataset_order():
     out = mp.Manager().dict()
     mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert out[0] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0] and out[1] is None
+
+
+def _world4_worker(rank, world, port, out):
+    """World 4: the two gradient buckets of engine.backward() and the deferred num_pos
+    normaliser with RAGGED per-rank positives (one rank has none), on the CPU process group."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import yunet_amd.engine as E
+    res = {}
+    for kind in ('n', 's'):
+        eng = E.YuNetEngine(O.yunet_arch(kind), 'cpu', world_size=world, process_group=None)
+        lay = eng.layout
+        # the cut of Plan.__init__: bucket A = the tail of the flat buffer from the first pyramid tap on
+        split_unit = f"backbone.model{min(eng.arch['out_idx'])}.conv1"
+        split_off = lay.units[split_unit]['off']
+        cut = E.LOG_HEAD + split_off
+        g = torch.Generator().manual_seed(77 + rank)
+        local = torch.randn(E.LOG_HEAD + lay.numel, generator=g)
+        every = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(every, local)
+        want = torch.stack(every).sum(0) / world
+        gb = eng.params.grad_buf
+        gb.copy_(local)
+        eng._allreduce_mean(gb[cut:])            # bucket A (side stream on the GPU)
+        eng._allreduce_mean(gb[:cut])            # bucket B + the logged scalars
+        split = gb.clone()
+        gb.copy_(local)
+        eng.allreduce_grads()                    # the unsplit form
+        res[kind] = dict(cut=cut, frac_a=float(lay.numel - split_off) / lay.numel,
+                         split_ok=bool(torch.allclose(split, want, atol=1e-6)),
+                         same_as_unsplit=bool(torch.allclose(split, gb, atol=1e-6)))   # (gloo chunks by message size: not bitwise)
+    # deferred normaliser: rank r holds num_pos_r / world; SUM over ranks = reduce_mean(num_pos) (yunet_head.py:493-497)
+    for name, npos in (('ragged', [37.0, 0.0, 5.0, 122.0]), ('none', [0.0, 0.0, 0.0, 0.0])):
+        norm = torch.tensor([npos[rank] / world, 0.0, npos[rank], 0.0])
+        eng.reduce_num_pos(norm)
+        n_total = max(float(norm[0]), 1.0)       # loss_finalize_ex: 1 / max(num_total, 1)
+        want_total = max(sum(npos) / world, 1.0)
+        res[name] = (abs(n_total - want_total) < 1e-6, float(norm[2]) == npos[rank])
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_world_size_4_buckets_and_ragged_num_pos():
+    world = 4
+    out = mp.Manager().dict()
+    mp.spawn(_world4_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert len(out) == world
+    for r in range(world):
+        for kind in ('n', 's'):
+            k = out[r][kind]
+            assert k['split_ok'] and k['same_as_unsplit'], (r, kind, k)
+            assert 0.5 < k['frac_a'] < 1.0, k          # most parameters ride in the overlapped bucket
+        assert all(out[r]['ragged']) and all(out[r]['none']), (r, out[r])
+    assert out[0]['n']['cut'] == out[3]['n']['cut']
+
+
+def _bn_bcast_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import yunet_amd
+    from yunet_amd.runner import broadcast_bn_buffers
+    cfg = yunet_amd.Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'configs', 'yunet_s.py'))
+    m = yunet_amd.build_detector(cfg.model)
+    with torch.no_grad():
+        for n, b in m.named_buffers():
+            if n.endswith('running_mean') or n.endswith('running_var'):
+                b.fill_(float(rank + 1))
+    sent = broadcast_bn_buffers(m)
+    vals = sorted({float(b.flatten()[0]) for n, b in m.named_buffers()
+                   if n.endswith('running_mean') or n.endswith('running_var')})
+    out[rank] = (sent, vals)
+    dist.destroy_process_group()
+
+
+def test_eval_hook_broadcasts_rank0_bn_buffers():
+    """DistEvalHook._do_evaluate (mmdet/core/evaluation/eval_hooks.py:101-107): before the sharded test every rank
+    takes rank 0's BatchNorm running statistics (per-rank BN otherwise evaluates `world` different models)."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_bn_bcast_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        sent, vals = out[r]
+        assert sent > 0 and vals == [1.0], (r, sent, vals)

@@ -99,12 +99,15 @@ def test_messages_bit_exact_between_two_processes_on_one_gpu():
 def _timeout_worker(rank, world, port, out):
     dev = _init(rank, world, port)
     from yunet_amd.oneshot import OneShotAllReduce
+    import yunet_amd._lib as L
     comm = OneShotAllReduce(dev, 4096)
     t = torch.full((16,), float(rank + 1), device=dev)
+    prev = L.set_option('oneshot_timeout_ms', 1000)      # the default is minutes
     if rank == 0:
-        comm.all_reduce_(t)          # rank 1 never sends: the wait gives up after ~3 s and leaves the buffer alone
+        comm.all_reduce_(t)          # rank 1 never sends: the wait gives up, sets the status word and poisons the buffer
     torch.cuda.synchronize()
-    out[rank] = dict(status=comm.status(), value=t.cpu().tolist())
+    L.set_option('oneshot_timeout_ms', prev)
+    out[rank] = dict(status=comm.status(), nan=bool(torch.isnan(t).all()), value=t.cpu().tolist(), default_ms=prev)
     dist.barrier()
     comm.close()
     dist.destroy_process_group()
@@ -114,8 +117,56 @@ def test_missing_peer_times_out_and_reports():
     world = 2
     out = mp.Manager().dict()
     mp.spawn(_timeout_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert out[0]['status'] == 1 and out[0]['value'] == [1.0] * 16
-    assert out[1]['status'] == 0
+    # loud on both channels: the host status word names the call, the buffer is NaN (never the un-reduced input)
+    assert out[0]['status'] == 1 and out[0]['nan'], out[0]
+    assert out[1]['status'] == 0 and out[1]['value'] == [2.0] * 16
+    assert out[0]['default_ms'] >= 60000, 'the default time-out is minutes, like the process group\'s'
+
+    
+def _engine_timeout_worker(rank, world, port, out):
+    """The training path must not continue on local gradients: the engine reads the status word every step."""
+    dev = _init(rank, world, port)
+    import yunet_amd
+    import yunet_amd._lib as L
+    import yunet_amd.synthetic as S
+    from yunet_amd.optim import FusedSGD
+    from yunet_amd.parallel import YuNetDistributedDataParallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yunet_amd.Config.fromfile(os.path.join(root, 'configs', 'yunet_s.py'))
+    model = yunet_amd.build_detector(cfg.model).to(dev).train()
+    ddp = YuNetDistributedDataParallel(model, device_ids=[0])
+    model.bind_engine(dev)
+    assert model.engine.enable_oneshot(verify=True)
+    opt = FusedSGD(model, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    b = S.to_device(S.make_batch(4, 160, 160, 100 + rank), dev)
+    L.set_option('oneshot_timeout_ms', 1000)
+    raised, first_loss = None, None
+    try:
+        for it in range(3):
+            if rank == 1 and it >= 1:
+                break                # rank 1 stops after the first step: rank 0's second step waits in vain
+            o = ddp.train_step(b, opt)
+            opt.zero_grad()
+            o['loss'].backward()
+            opt.step()
+            torch.cuda.synchronize()
+            if it == 0:
+                first_loss = float(o['log_vars']['loss'])
+    except RuntimeError as e:
+        raised = str(e)
+    out[rank] = dict(raised=raised, first_loss=first_loss, status=model.engine.oneshot_status())
+    dist.barrier()
+    model.engine.disable_oneshot()
+    dist.destroy_process_group()
+
+
+def test_engine_raises_when_a_peer_goes_missing():
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_engine_timeout_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0]['first_loss'] == out[0]['first_loss'], 'the first (complete) step is finite'
+    assert out[0]['raised'] and 'one-shot all-reduce' in out[0]['raised'], out[0]
+    assert out[0]['status'] > 0 and out[1]['raised'] is None
 
 
 def _engine_worker(rank, world, port, out):

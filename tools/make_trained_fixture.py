@@ -4,7 +4,7 @@ on one MI355X and store the state_dict as tests/golden/yunet_n_synth_trained.pth
 "trained-checkpoint-like" weights bench.py loads so that SimOTA runs with dynamic_k > 1 (SURVEY 8d:
 a randomly initialised network gives k = 1 for 90 % of the GTs).
 
-    python tools/make_trained_fixture.py [--iters 3000] [--batch 64]
+    python tools/make_trained_fixture.py [--kind n|s] [--iters 3000] [--batch 64]
 """
 import argparse
 import os
@@ -25,10 +25,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=3000)
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden', 'yunet_n_synth_trained.pth'))
+    ap.add_argument('--kind', default='n', choices=['n', 's'])
+    ap.add_argument('--out', default=None)
     a = ap.parse_args()
+    a.out = a.out or os.path.join(ROOT, 'tests', 'golden', f'yunet_{a.kind}_synth_trained.pth')
     dev = torch.device('cuda', 0)
-    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'yunet_n.py'))
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', f'yunet_{a.kind}.py'))
     torch.manual_seed(0)
     model = yunet_amd.build_detector(cfg.model).to(dev).train()
     opt = FusedSGD(model, lr=0.01, momentum=0.9, weight_decay=5e-4)
