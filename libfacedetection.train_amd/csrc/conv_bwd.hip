@@ -2249,6 +2249,9 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
                                           : launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
         if (d->cin == 32) return full816 ? launch_dp_bwd<32, 64, 8, 16, false, 0, true, true>(d, s)
                                          : launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
+        // (option bwd_fp32mma: the exact-fp32 matrix instruction for this instance too -- before round 5 the pooled-dy
+        // 64 -> 64 unit stayed on the split-bf16 kernel even with the option set)
+        if (yunet_options().bwd_fp32mma != 0) return launch_dp_bwd<64, 64, 8, 16, false, 0, true>(d, s);
         return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, true>(d, s) : launch_dp_bwd64<8, false, true>(d, s);
     }
 #define DP_CASE(ci, co) \

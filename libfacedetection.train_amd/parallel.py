@@ -16,17 +16,54 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def launcher_env(launcher, env=None, first_host=None):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT for the three launchers mmcv's init_dist knows
+    (mmcv/runner/dist_utils.py, un-vendored; SURVEY App. C): 'pytorch' -- torch.distributed.run / launch export them;
+    'slurm' -- SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID, the master is the first host of SLURM_NODELIST (port
+    29500 unless MASTER_PORT is set); 'mpi' -- OMPI_COMM_WORLD_RANK / _SIZE / _LOCAL_RANK.  Pure function of `env`
+    (tests); `first_host` resolves a node list to its first host name (default: `scontrol show hostname`)."""
+    env = os.environ if env is None else env
+    out = {}
+    if launcher == 'slurm':
+        out['RANK'] = str(int(env['SLURM_PROCID']))
+        out['WORLD_SIZE'] = str(int(env['SLURM_NTASKS']))
+        out['LOCAL_RANK'] = str(int(env.get('SLURM_LOCALID', 0)))
+        if 'MASTER_ADDR' not in env:
+            nodes = env.get('SLURM_NODELIST') or env.get('SLURM_JOB_NODELIST') or '127.0.0.1'
+            if first_host is None:
+                def first_host(n):
+                    import subprocess
+                    try:
+                        return subprocess.check_output(['scontrol', 'show', 'hostname', n], text=True).split()[0]
+                    except Exception:          # noqa: BLE001 -- no scontrol: a plain host name works as is
+                        return n.split(',')[0]
+            out['MASTER_ADDR'] = first_host(nodes)
+    elif launcher == 'mpi':
+        out['RANK'] = str(int(env['OMPI_COMM_WORLD_RANK']))
+        out['WORLD_SIZE'] = str(int(env['OMPI_COMM_WORLD_SIZE']))
+        out['LOCAL_RANK'] = str(int(env.get('OMPI_COMM_WORLD_LOCAL_RANK', 0)))
+    elif launcher != 'pytorch':
+        raise ValueError(f'Invalid launcher type: {launcher}')
+    if 'MASTER_ADDR' not in env and 'MASTER_ADDR' not in out:
+        out['MASTER_ADDR'] = '127.0.0.1'
+    if 'MASTER_PORT' not in env:
+        out['MASTER_PORT'] = '29500'
+    return out
+
+
 def init_dist(launcher='pytorch', backend='nccl', **kwargs):
     """tools/train.py:163-170 -> mmcv init_dist.  'nccl' is RCCL on ROCm."""
     if dist.is_initialized():
         return
+    os.environ.update(launcher_env(launcher))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', rank))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / peer-mapped inboxes across processes
     if backend == 'nccl' and torch.cuda.is_available():
-        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+        dev = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(dev)
+        kwargs.setdefault('device_id', dev)                      # bind the communicator to this GPU
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
 
 

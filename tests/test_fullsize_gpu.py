@@ -257,6 +257,18 @@ def test_full_step_vs_oracle(kind, h, n, seed, weights):
             assert torch.allclose(sd_g[k], v, rtol=1e-3, atol=1e-4), k
 
 
+def test_full_step_vs_oracle_exact_fp32_backward():
+    """bench.py's `exact_fp32_bwd` configuration -- the trained fixture, bs 256, dispatcher option bwd_fp32mma = 1 (every
+    backward GEMM of the 64 -> 64 units on the exact-fp32 matrix instruction, incl. the pooled-dy and the packed
+    instances) -- against the same oracle fixture and the same bars as the default path."""
+    import yunet_amd._lib as L
+    prev = L.set_option('bwd_fp32mma', 1)
+    try:
+        test_full_step_vs_oracle('n', 320, 256, 14, 'trained')
+    finally:
+        L.set_option('bwd_fp32mma', prev)
+
+
 def _full_step_vs_live_oracle(kind, h, n, seed, weights):
     """The same comparison with the whole oracle step (fp32 conv stack + fp64 gradient yardstick) evaluated live on the
     host: what test_full_step_vs_oracle did before round 4; minutes of host time per case."""

@@ -353,8 +353,14 @@ def test_bench_byte_model_matches_survey_figures():
     pw_flops = sum(bench.op_flops(op, L) for op in plan.fwd_a if op.opcode == L.OP_DP_FWD)
     assert pw_flops / n / 2 / 1e6 == pytest.approx(135.6 * 0.765, rel=0.03)
     # the committed PMC table is found and keyed by the names bench.py prints
-    traffic, src = bench.pmc_traffic('dp_bwd64_kernel<8,false,false>')
+    # (a kernel FAMILY: {template instance: launches per step}, the mean is weighted by the launches)
+    traffic, src = bench.pmc_traffic({'dp_bwd64_kernel<8,false,false>': 1})
     assert traffic is not None and traffic > 1e8 and src.endswith('_pmc_traffic.json')
+    both, _ = bench.pmc_traffic({'dp_bwd64_kernel<8,false,false>': 1, 'dp_bwd64_kernel<4,false,false>': 4})
+    small, _ = bench.pmc_traffic({'dp_bwd64_kernel<4,false,false>': 4})
+    assert both == pytest.approx((traffic + 4 * small) / 5, rel=1e-6)
+    assert bench.pmc_traffic({'no_such_kernel<1>': 1}) == (None, None)
+    assert bench.family_of('dp_bwd64_kernel<8,false,true>') == 'dp_bwd64_kernel' and bench.family_of('loss_kernel') == 'loss_kernel'
 
 
 def test_bbox_mapping_back_matches_reference():

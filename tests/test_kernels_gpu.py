@@ -115,10 +115,39 @@ def test_dp_fwd(cin, cout, with_in_bn):
             assert rel_err(out_stats, sr) < 2e-5
 
 
+@pytest.fixture
+def exact_fp32_backward():
+    """Dispatcher option bwd_fp32mma = 1 (include/yunet_hip.h): every backward GEMM of the 64 -> 64 units on the
+    exact-fp32 matrix instruction -- the variant bench.py times as `exact_fp32_bwd` (that number
+    came from a dispatch no test drove)."""
+    import yunet_amd._lib as L
+    prev = L.set_option('bwd_fp32mma', 1)
+    yield
+    L.set_option('bwd_fp32mma', prev)
+
+
+@pytest.mark.parametrize('mode', ['bn_bn', 'id_bn', 'bn_nobn'])
+def test_dp_bwd_exact_fp32mma(mode, exact_fp32_backward):
+    """test_dp_bwd[64-64-*] with bwd_fp32mma = 1: dp_bwd_kernel<64,64,8,16,PACKED,GEMM=0> on the plain 80 x 80 /
+    40 x 40 maps and the packed 20 x 20 canvas (BIG_SHAPES walks > 256 tiles per workgroup grid).  Same fp64 yardstick;
+    the bar is the forward kernels' 2e-5 (the split-bf16 default gets 5e-5)."""
+    _dp_bwd_case(64, 64, mode, tol=2e-5)
+
+
+def test_fused_pooling_exact_fp32mma(exact_fp32_backward):
+    """The pooled-dy 64 -> 64 instance (80 x 80 -> 40 x 40 in the shipped nets) with bwd_fp32mma = 1:
+    dp_bwd_kernel<64,64,8,16,false,0,true> (before round 5 this instance ignored the option)."""
+    test_fused_pooling(64, 64, 20, 80, 80)
+
+
 @pytest.mark.parametrize('cin,cout', CHANNELS)
 @pytest.mark.parametrize('mode', ['bn_bn', 'id_bn', 'bn_nobn'])
 def test_dp_bwd(cin, cout, mode):
     """dx / dW1 / db1 / dW2 / db2 and the producer's BN-backward sums vs fp64 autograd."""
+    _dp_bwd_case(cin, cout, mode, tol=5e-5)
+
+
+def _dp_bwd_case(cin, cout, mode, tol):
     k = K()
     g = torch.Generator().manual_seed(7 + cin * 100 + cout)
     in_bn_on = mode.startswith('bn')
@@ -167,7 +196,6 @@ def test_dp_bwd(cin, cout, mode):
             w_dw.detach().float().to(DEV).view(cout, 9).contiguous(), b_dw.detach().float().to(DEV),
             zg, dyg, in_bn, out_bn, dy_scale=dy_scale)
         torch.cuda.synchronize()
-        tol = 5e-5
         assert rel_err(nchw(dx.cpu()), b_in.grad) < tol, ('dx', n, h, w)
         # per input channel; bar = 4x the max-norm bar: a channel's own maximum is up to ~4x
         # below the tensor's at these channel counts
