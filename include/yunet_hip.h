@@ -421,6 +421,7 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "fwd16s"             1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernels | 0: the tile kernels
  *   "stem_mma"           1 (default): the fp32 stem (yunet_stem_fwd; YUNET_OP_STEM_BWD with the stem's parameters in p[4],
  *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
+ *   "upadd_coarse"       1 (default): yunet_upadd_bwd with dxa = NULL on the dedicated coarse-gradient kernel | 0: general kernel
  *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 600 000; env YUNET_ONESHOT_TIMEOUT_MS)
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */

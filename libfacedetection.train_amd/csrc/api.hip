@@ -98,6 +98,7 @@ YunetOptions& yunet_options() {
         v.bwd16s_rows = env("YUNET_BWD16S_ROWS", 0);
         v.stem_mma = env("YUNET_STEM_MMA", 1);
         v.fwd16s = env("YUNET_FWD16S", 1);
+        v.upadd_coarse = env("YUNET_UPADD_COARSE", 1);
         v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 600000);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
@@ -120,6 +121,7 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "bwd16s_rows")) slot = &o.bwd16s_rows;
     else if (!strcmp(name, "stem_mma")) slot = &o.stem_mma;
     else if (!strcmp(name, "fwd16s")) slot = &o.fwd16s;
+    else if (!strcmp(name, "upadd_coarse")) slot = &o.upadd_coarse;
     else if (!strcmp(name, "oneshot_timeout_ms")) slot = &o.oneshot_timeout_ms;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;

@@ -2084,6 +2084,69 @@ __global__ __launch_bounds__(256) void upadd_bwd_kernel(const act_t* __restrict_
 #undef UPADD_FLUSH
 }
 
+// The coarse gradient alone (dxa == NULL: the fine tensor's share of a pyramid tap is applied by pool_bwd_kernel,
+// DESIGN 3): dxb = mask_b (sum of the 2 x 2 fine gradients) + the coarse BatchNorm's backward sums.  Round 5: the
+// general kernel above compiled `if (on) sum += ...` of its 16 channel lanes into exec-mask branches around fp64 adds
+// and separated a thread's four fine loads by them (3.3 TB/s); here the four loads + the coarse z are issued together
+// and the mask is a select (adding the +0.0 of a masked-out element leaves every sum unchanged: same values, same
+// order of additions as the general kernel).
+__global__ __launch_bounds__(256) void upadd_bwd_coarse_kernel(const act_t* __restrict__ zb, YunetBN bnb,
+                                                               const float* __restrict__ dout, float* __restrict__ dxb,
+                                                               int acc_b, int N, int H, int W, int C) {
+    const int C4 = C / 4, Hb = H / 2, Wb = W / 2;
+    const long long total = (long long)N * Hb * Wb * C4;
+    const int c4 = threadIdx.x % C4;
+    __shared__ float s_tb[5 * 64];
+    bn_table_fill(s_tb, bnb, C, threadIdx.x);
+    __syncthreads();
+    BNCoef kb[4];
+    bn_table_get(s_tb, C, c4 * 4, kb);
+    double bsb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsb[i] = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long pix = e / C4;
+        const int bx = (int)(pix % Wb);
+        pix /= Wb;
+        const int by = (int)(pix % Hb), n = (int)(pix / Hb);
+        const size_t off0 = (((size_t)n * H + 2 * by) * W + 2 * bx) * C + c4 * 4;
+        const size_t offb = (((size_t)n * Hb + by) * Wb + bx) * C + c4 * 4;
+        const float4 g0 = *reinterpret_cast<const float4*>(dout + off0);
+        const float4 g1 = *reinterpret_cast<const float4*>(dout + off0 + C);
+        const float4 g2 = *reinterpret_cast<const float4*>(dout + off0 + (size_t)W * C);
+        const float4 g3 = *reinterpret_cast<const float4*>(dout + off0 + (size_t)W * C + C);
+        const float4 zb4 = act_ld4(zb + offb);
+        float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (acc_b) old = *reinterpret_cast<const float4*>(dxb + offb);
+        const float sum[4] = {((0.f + g0.x) + g1.x) + g2.x + g3.x, ((0.f + g0.y) + g1.y) + g2.y + g3.y,
+                              ((0.f + g0.z) + g1.z) + g2.z + g3.z, ((0.f + g0.w) + g1.w) + g2.w + g3.w};
+        const float zbv[4] = {zb4.x, zb4.y, zb4.z, zb4.w};
+        float ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = bnrelu(zbv[i], kb[i].mean, kb[i].scale, kb[i].beta) > 0.0f;
+            ob[i] = on ? sum[i] : 0.0f;
+            const float xh = on ? bn_center(zbv[i], kb[i].mean, kb[i].mean_lo) * kb[i].invstd : 0.0f;
+            bsb[i] += (double)ob[i];
+            bsb[4 + i] += (double)(ob[i] * xh);
+        }
+        float4 v = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        if (acc_b) { v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+        *reinterpret_cast<float4*>(dxb + offb) = v;
+    }
+    __shared__ double red[256 * 8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = bsb[i];
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C && bnb.bstats) {
+        const int which = threadIdx.x / C, c = threadIdx.x % C;
+        const int q = c >> 2, kk = (c & 3) + 4 * which;
+        double v = 0.0;
+        for (int p = 0; p < 256 / C4; ++p) v += red[(p * C4 + q) * 8 + kk];
+        atomic_add_f64(bn_slot(bnb.bstats, bnb.slots, C) + which * C + c, v);
+    }
+}
+
 #ifndef YUNET_ACT_BF16
 __global__ void bn_param_grad_kernel(const double* __restrict__ bstats, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, int C, int accumulate) {
@@ -2330,6 +2393,11 @@ extern "C" int ACT_SUFFIX(yunet_upadd_bwd)(const float* za, const YunetBN* bna, 
                                            void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    if (!dxa && yunet_options().upadd_coarse) {        // the coarse gradient alone: dedicated kernel (round 5)
+        hipLaunchKernelGGL(upadd_bwd_coarse_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const act_t*>(zb), *bnb, dout, dxb, accumulate_b, N, H, W, C);
+        return hip_status();
+    }
     hipLaunchKernelGGL(upadd_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const act_t*>(za), *bna, reinterpret_cast<const act_t*>(zb), *bnb, dout, dxa,
                        accumulate_a, dxb, accumulate_b, N, H, W, C);

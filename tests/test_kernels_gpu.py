@@ -459,6 +459,23 @@ def test_tap_gradient_written_once(n, h, w, c):
     k.pool_bwd(zag, bna1, dp, dx=dxa2, accumulate=True, extra=dm)
     torch.cuda.synchronize()
     assert torch.equal(dxa2, base + dxa1)
+    # round 5: skip_a runs the dedicated coarse-gradient kernel (upadd_bwd_coarse_kernel); the general kernel behind the
+    # option gives the same bits, and accumulate_b adds onto an existing coarse gradient
+    import yunet_amd._lib as L
+    prev = L.set_option('upadd_coarse', 0)
+    try:
+        bna3, bnb3 = bns()
+        _, dxb3 = k.upadd_bwd(zag, bna3, zbg, bnb3, dm, skip_a=True)
+        torch.cuda.synchronize()
+    finally:
+        L.set_option('upadd_coarse', prev)
+    assert torch.equal(dxb3, dxb1) and torch.equal(bnb3.bstats, bnb1.bstats)
+    baseb = torch.randn(zbg.shape, device=DEV)
+    dxb4 = baseb.clone()
+    bna4, bnb4 = bns()
+    k.upadd_bwd(zag, bna4, zbg, bnb4, dm, dxb=dxb4, acc_b=True, skip_a=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dxb4, baseb + dxb1)
 
 
 def _replicas(v, slots, g):
