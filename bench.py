@@ -760,7 +760,10 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
             'data': 'synthetic' if not trained else 'synthetic (face patterns painted over noise at the GT boxes)',
             'config': {'workload': f'YuNet_{a.kind} {a.size}x{a.size} bs={a.batch}/GPU full training step, ' +
-                                   ('fp32 (64->64 backward GEMMs: split-bf16, 2^-17; exact variant in exact_fp32_bwd)'
+                                   ('fp32 (64->64 backward GEMMs: two-way bf16 split -- measured against the exact-fp32 instruction: every output '
+                                    'within 9e-6 of its tensor maximum, 50 SGD iterations end as far from the exact path as a '
+                                    'last-bit perturbation of it does, tests/test_precision_gpu.py + profiles/r05_precision.json; '
+                                    'the strictly-fp32 variant is timed in exact_fp32_bwd)'
                                     if a.dtype == 'f32' else
                                     'bf16 activations + bf16 forward matrix instruction, fp32 gradients / weights') +
                                    ': fwd + SimOTA + losses + bwd + grad all-reduce + SGD, synthetic WIDER-Face-shaped '

@@ -1020,6 +1020,9 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0));
 #endif
 }
+#ifndef YUNET_BWD64_ADDR2
+#define YUNET_BWD64_ADDR2 1
+#endif
 namespace bwd64 {
 constexpr int C = 64, C4 = 16;
 constexpr int PLANE_PX = 128;      // (pixels of the largest tile: plane_off() only needs the row pitch)
@@ -1083,6 +1086,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     using namespace bwd64;
     using G = Geo<NW>;
+    constexpr bool ADDR2 = !PACKED && (YUNET_BWD64_ADDR2 != 0);      // round 5: shift-only halo addressing (issue2)
     constexpr int NT = G::NT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, IP = G::IP, NDZ = G::NDZ, NX = G::NX;
     constexpr int PSTEP = G::PSTEP, PLANE = G::PLANE, OFF_DZ = G::OFF_DZ, OFF_X = G::OFF_X, OFF_P = G::OFF_P;
     constexpr int OFF_A = G::OFF_A, WORKB = G::WORKB, KSPLIT = G::KSPLIT, MH = G::MH;
@@ -1236,6 +1240,111 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // ---- round 5 (ADDR2, unpacked maps): the same loads with a shift-only thread -> halo-slot mapping ------------------
+    // The old mapping (halo pixel hp = tid / 16 + 32 i, row hp / 18) cost a division by the halo width, ~15 vector and
+    // ~15 scalar instructions per load -- 16 loads per thread and tile, a quarter of the tile's VALU work, and every one
+    // of the four issue pieces decomposed the tile index again.  Here the halo [TH + 2][TW + 2] is split into its TW-wide
+    // main part -- pixel slot ps = tid / 16 of pass i < 5 is halo row 2 i + (ps >> log2 TW), column ps & (TW - 1) -- and
+    // the two extra columns TW, TW + 1 (pass 5: row ps >> 1, column TW + (ps & 1); with NW = 4 their rows 8, 9 are the
+    // one-float-per-thread remainder): a thread's element offset is ONE tile-invariant value `tm` plus a scalar per
+    // (tile, pass), the interior loads use the same `tm`, and a uniform branch drops every per-element validity test
+    // when the whole halo lies inside the image (48 % of the 80 x 80 tiles, 36 % at 40 x 40).
+    constexpr int XSH = NW == 8 ? 4 : 3;                    // log2(TW)
+    constexpr int NEXTRA = NW == 8 ? 20 : 16;               // halo pixels of the extra pass (NW = 8: 20 of 32 slots)
+    static_assert(!ADDR2 || (NDZ == 6 && NX == 4 && PSTEP == 2 * TW && (1 << XSH) == TW), "ADDR2 pass geometry");
+    auto issue2 = [&](int t, auto part_c) {
+        constexpr int PART = decltype(part_c)::value;
+        const int tid = opaque((int)threadIdx.x);
+        const int och4 = tid & 15, ps = tid >> 4;
+        const int r = ps >> XSH, hxm = ps & (TW - 1);
+        const int n = t / tiles_img, rr = t - n * tiles_img;
+        const int ty = rr / tiles_x;
+        const int y0 = ty * TH, x0 = (rr - ty * tiles_x) * TW;
+        const size_t zbase = (size_t)n * d.z_img_stride, xbase = (size_t)n * d.x_img_stride;
+        const auto r_dy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(d.dy) + (POOLDY ? (size_t)n * (pooledbytes / 4u) : zbase), 0, POOLDY ? pooledbytes : dybytes, 0x00020000);
+        const auto r_id = __builtin_amdgcn_make_buffer_rsrc(
+            d.pool_idx + (POOLDY ? (size_t)n * (pooledbytes / 4u) : (size_t)0), 0, POOLDY ? pooledbytes / 4u : 0u, 0x00020000);
+        const auto r_z = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zbytes, 0x00020000);
+        const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xbytes, 0x00020000);
+        const bool inner = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + TW < W;      // uniform: the halo is inside the image
+        if (PART <= 0) okmask = 0;
+        const int tm = (r * W + hxm) * C + och4 * 4;              // elements from slot (row 0, column 0) of a pass
+        const int hbase = ((y0 - 1) * W + (x0 - 1)) * C;          // halo origin (negative on the top / left border: masked)
+        // pooled dy: halo slot (hy, hx) reads the pooled element ((y0 - 1 + hy) >> 1, (x0 - 1 + hx) >> 1); y0, x0 even
+        const int tq = (r * Wq + ((hxm - 1) >> 1)) * C + och4 * 4;
+        const int qbase = (((y0 >> 1) - 1) * Wq + (x0 >> 1)) * C;
+        auto ld = [&](int i, bool ok, unsigned eo, unsigned eq) {
+            if constexpr (POOLDY) {
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+                pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
+            } else {
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dybytes, 0, 0);
+                pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+            }
+            pz[i] = act_raw4{};
+            if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zbytes);
+        };
+        auto body = [&](auto inner_c) {
+            constexpr bool INNER = decltype(inner_c)::value;
+            const bool xok_m = INNER || (unsigned)(x0 - 1 + hxm) < (unsigned)W;
+#pragma unroll
+            for (int i = 0; i < NDZ; ++i) {
+                if (PART >= 0 && PART != 1 + (3 * i) / NDZ) continue;
+                if (i < 5) {
+                    const bool ok = INNER || (xok_m && (unsigned)(y0 - 1 + 2 * i + r) < (unsigned)H);
+                    okmask |= ok ? (1u << i) : 0u;
+                    ld(i, ok, (unsigned)(hbase + i * 2 * W * C + tm), (unsigned)(qbase + i * Wq * C + tq));
+                } else {
+                    const int hy = ps >> 1, hx = TW + (ps & 1);
+                    const bool ok = ps < NEXTRA && (INNER || ((unsigned)(y0 - 1 + hy) < (unsigned)H &&
+                                                              (unsigned)(x0 - 1 + hx) < (unsigned)W));
+                    okmask |= ok ? (1u << i) : 0u;
+                    ld(i, ok, (unsigned)(hbase + (hy * W + hx) * C + och4 * 4),
+                       (unsigned)(qbase + ((((hy - 1) >> 1) + 1) * Wq + ((hx - 1) >> 1)) * C + och4 * 4));
+                }
+            }
+            if constexpr (G::REM) {
+                if (PART < 0 || PART == 3) {
+                    const int j = tid >> 6, ch = tid & 63;
+                    const int hy = TH + (j >> 1), hx = TW + (j & 1);
+                    const bool ok = INNER || ((unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W);
+                    const unsigned eo = (unsigned)(hbase + (hy * W + hx) * C + ch);
+                    okmask |= ok ? (1u << NDZ) : 0u;
+                    if constexpr (POOLDY) {
+                        const unsigned eq = (unsigned)(qbase + ((((hy - 1) >> 1) + 1) * Wq + ((hx - 1) >> 1)) * C + ch);
+                        rem_dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eq * 4u : pooledbytes, 0, 0));
+                        rem_id = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_id, ok ? eq : pooledbytes, 0, 0) & 0xffu;
+                    } else {
+                        rem_dy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eo * 4u : dybytes, 0, 0));
+                    }
+                    rem_z = 0.0f;
+                    if (bn_out) rem_z = act_bufld1(r_z, ok ? eo * ACT_B : zbytes);
+                }
+            }
+        };
+        if (PART != 0) {
+            if (inner) body(std::true_type{});
+            else body(std::false_type{});
+        }
+        if (PART <= 0) {
+            // raw x over the tile: pass i covers tile rows 2 i, 2 i + 1 -- the same `tm`
+            const bool tfull = y0 + TH <= H && x0 + TW <= W;
+            const int xb = (y0 * W + x0) * C;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const bool ok = tfull || (y0 + 2 * i + r < H && x0 + hxm < W);
+                px[i] = act_bufld4(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes);
+            }
+        }
+    };
+    auto issue_any = [&](int t, auto part_c) {
+        if constexpr (ADDR2) issue2(t, part_c);
+        else issue(t, part_c);
+    };
     using All = std::integral_constant<int, -1>;
     int t = first_tile();
 
@@ -1260,7 +1369,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) rt[kb][j] = d.w_pw[(32 * kb + 8 * g + j) * C + ci];
         }
-        if (t < ntiles) issue(t, All{});
+        if (t < ntiles) issue_any(t, All{});
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const float w8[8] = {ra[kb].x, ra[kb].y, ra[kb].z, ra[kb].w, rb[kb].x, rb[kb].y, rb[kb].z, rb[kb].w};
@@ -1334,6 +1443,53 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             const float4 o_dh = *reinterpret_cast<float4*>(s_co + 2 * C + och4 * 4);
             const float4 o_dl = *reinterpret_cast<float4*>(s_co + 3 * C + och4 * 4);
             const int hp0 = tid / C4;
+            if constexpr (ADDR2) {
+                // the slots of issue2: pass i < 5 -> halo row 2 i + r, column hxm; pass 5 -> the two extra columns
+                const int ps = tid >> 4, r = ps >> XSH, hxm = ps & (TW - 1);
+                const bool inner = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + TW < W;
+                float* const lm = s_dz + (r * HW_ + hxm) * C + och4 * 4;
+                auto fold = [&](auto inner_c) {
+                    constexpr bool INNER = decltype(inner_c)::value;
+#pragma unroll
+                    for (int i = 0; i < NDZ; ++i) {
+                        const int hy = ps >> 1, hx = TW + (ps & 1);         // (pass 5)
+                        if (i < 5 || ps < NEXTRA) {
+                            float4 dy = pdy[i];
+                            const float4 z = act_unpack(pz[i]);
+                            if constexpr (POOLDY) {
+                                // window position of the slot: y0, x0 are even, so the parities are the slot's own
+                                const unsigned pos = i < 5 ? (unsigned)(((r ^ 1) << 1) | ((hxm + 1) & 1))
+                                                           : (unsigned)((((hy + 1) & 1) << 1) | ((ps & 1) ^ 1));
+                                const unsigned id = pid[i];
+                                dy.x = (id & 0xffu) == pos ? dy.x : 0.0f;
+                                dy.y = ((id >> 8) & 0xffu) == pos ? dy.y : 0.0f;
+                                dy.z = ((id >> 16) & 0xffu) == pos ? dy.z : 0.0f;
+                                dy.w = (id >> 24) == pos ? dy.w : 0.0f;
+                            }
+                            // zero padding of dz: a slot outside the image loaded dy = z = 0, which the BN backward
+                            // would turn into D
+                            const bool ok = INNER || ((okmask >> i) & 1u);
+                            float4 v;
+                            v.x = ok ? fmaf(o_a.x, dy.x, fmaf(o_b.x, z.x, o_dh.x)) + o_dl.x : 0.0f;
+                            v.y = ok ? fmaf(o_a.y, dy.y, fmaf(o_b.y, z.y, o_dh.y)) + o_dl.y : 0.0f;
+                            v.z = ok ? fmaf(o_a.z, dy.z, fmaf(o_b.z, z.z, o_dh.z)) + o_dl.z : 0.0f;
+                            v.w = ok ? fmaf(o_a.w, dy.w, fmaf(o_b.w, z.w, o_dh.w)) + o_dl.w : 0.0f;
+                            float* dst = i < 5 ? lm + i * 2 * HW_ * C : s_dz + (hy * HW_ + hx) * C + och4 * 4;
+                            *reinterpret_cast<float4*>(dst) = v;
+                        }
+                    }
+                    if constexpr (G::REM) {
+                        const int j = tid >> 6, ch = tid & 63;
+                        const int hp = (TH + (j >> 1)) * HW_ + TW + (j & 1);
+                        float dyv = rem_dy;
+                        if constexpr (POOLDY) dyv = rem_id == (unsigned)((((j >> 1) ^ 1) << 1) | ((j & 1) ^ 1)) ? dyv : 0.0f;
+                        const bool ok = INNER || ((okmask >> NDZ) & 1u);
+                        s_dz[hp * C + ch] = ok ? fmaf(s_co[ch], dyv, fmaf(s_co[C + ch], rem_z, s_co[2 * C + ch])) + s_co[3 * C + ch] : 0.0f;
+                    }
+                };
+                if (inner) fold(std::true_type{});
+                else fold(std::false_type{});
+            } else {
 #pragma unroll
             for (int i = 0; i < NDZ; ++i) {
                 const int hp = hp0 + PSTEP * i;
@@ -1364,6 +1520,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 if constexpr (POOLDY) dyv = rem_id == ((posmask >> (2 * NDZ)) & 3u) ? dyv : 0.0f;
                 const bool ok = (okmask >> NDZ) & 1u;
                 s_dz[hp * C + ch] = ok ? fmaf(s_co[ch], dyv, fmaf(s_co[C + ch], rem_z, s_co[2 * C + ch])) + s_co[3 * C + ch] : 0.0f;
+            }
             }
             if constexpr (PACKED) {
                 for (int ip = tid; ip < IP; ip += NT) {
@@ -1437,7 +1594,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         // next tile's loads go out in four pieces from here on (the p GEMM above runs with no load in flight: a
         // CU cannot keep a whole tile's 124 KB in flight, and the in-order vector-memory queue would hold any
         // scratch access behind them)
-        if (more) issue(t + gridDim.x, std::integral_constant<int, 0>{});
+        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 0>{});
 
         // ---- depthwise backward on the VALU (sliding window over a 4-row column); dp stays in registers -------------
         float4 dp[4];
@@ -1495,7 +1652,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
             }
         }
-        if (more) issue(t + gridDim.x, std::integral_constant<int, 1>{});
+        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 1>{});
         __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
         {
             const int cq = opaque((int)threadIdx.x) % C4;
@@ -1512,7 +1669,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
         __syncthreads();
         DP_BWD64_STAMP(2);
-        if (more) issue(t + gridDim.x, std::integral_constant<int, 2>{});
+        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 2>{});
 
         // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
         // k index of lane group G, element e (0..7): pixel 32 kb + 4 * (4 (G >> 1) + 2 (e >> 2) + (G & 1)) + (e & 3) --
@@ -1546,7 +1703,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
         DP_BWD64_STAMP(3);
-        if (more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
+        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
         // Everything a step needs is requested before the step that consumes it (operands of both k blocks, then the
