@@ -246,7 +246,10 @@ int yunet_assign_ex(const float* flat, const float* pre_scores, const float* pre
  * to be all-reduced by the caller when world > 1), norm[1] = sum_n kps weight. */
 int yunet_loss_norm(const float* img_stats, int N, float inv_world, float* norm, void* stream);
 
-enum { YUNET_BOX_EIOU = 0, YUNET_BOX_DIOU = 1 };
+/* box losses of mmdet/models/losses/iou_loss.py: EIoULoss :194-227 | DIoULoss :137-172 | IoULoss :14-50 (mode linear /
+ * square / log; YuNet_Head's own default is mode 'square', yunet_head.py:59-64) | GIoULoss :103-120 | CIoULoss :230-293 */
+enum { YUNET_BOX_EIOU = 0, YUNET_BOX_DIOU = 1, YUNET_BOX_IOU_LINEAR = 2, YUNET_BOX_IOU_SQUARE = 3, YUNET_BOX_IOU_LOG = 4,
+       YUNET_BOX_GIOU = 5, YUNET_BOX_CIOU = 6 };
 typedef struct YunetLossCfg {
     int32_t box_loss;            /* YUNET_BOX_*  (losses/iou_loss.py:194-227 / 137-172) */
     float w_cls, w_box, w_obj, w_kps;   /* loss_weight of each term                    */

@@ -15,7 +15,7 @@ MAX_LEVELS = 5
 
 T_IDENTITY, T_BNRELU = 0, 1
 F32, BF16 = 0, 1
-BOX_EIOU, BOX_DIOU = 0, 1
+BOX_EIOU, BOX_DIOU, BOX_IOU_LINEAR, BOX_IOU_SQUARE, BOX_IOU_LOG, BOX_GIOU, BOX_CIOU = 0, 1, 2, 3, 4, 5, 6
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
  OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH, OP_FORK, OP_JOIN) = range(1, 22)

@@ -499,6 +499,77 @@ __device__ D4 diou(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float
     return mk(1.0f) - (ious - rho2 / c2);
 }
 
+// ---- the other members of the reference's IoU-loss family (round 5: YuNet_Head's own default is IoULoss(mode='square'),
+// yunet_head.py:59-64; the registry also offers GIoULoss / CIoULoss) -------------------------------------------------
+__device__ __forceinline__ D4 dlog(D4 a) {
+    D4 r; r.v = logf(a.v);
+    const float inv = 1.0f / a.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * inv;
+    return r;
+}
+__device__ __forceinline__ D4 datan(D4 a) {
+    D4 r; r.v = atanf(a.v);
+    const float k = 1.0f / (1.0f + a.v * a.v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * k;
+    return r;
+}
+// bbox_overlaps(pred, target, is_aligned=True, eps) of iou2d_calculator.py:214-259: IoU and the union it used
+__device__ __forceinline__ D4 aligned_iou(D4 px1, D4 py1, D4 px2, D4 py2, D4 tx1, D4 ty1, D4 tx2, D4 ty2, float eps,
+                                          D4* uni_out) {
+    const D4 w = dclamp0(dmin(px2, tx2) - dmax(px1, tx1));
+    const D4 h = dclamp0(dmin(py2, ty2) - dmax(py1, ty1));
+    const D4 overlap = w * h;
+    const D4 a1 = (px2 - px1) * (py2 - py1), a2 = (tx2 - tx1) * (ty2 - ty1);
+    const D4 uni = dmax((a1 + a2) - overlap, mk(eps));          // torch.max(union, eps)
+    *uni_out = uni;
+    return overlap / uni;
+}
+// iou_loss, iou_loss.py:14-50: mode 0 linear | 1 square | 2 log; `eps` clamps the IoU from below
+__device__ D4 iou_family(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float tx2f, float ty2f, int mode, float eps) {
+    D4 uni;
+    D4 ious = aligned_iou(px1, py1, px2, py2, mk(tx1f), mk(ty1f), mk(tx2f), mk(ty2f), 1e-6f, &uni);
+    if (!(ious.v >= eps)) ious = mk(eps);                       // .clamp(min=eps): the gradient passes at the boundary
+    if (mode == 0) return mk(1.0f) - ious;
+    if (mode == 1) return mk(1.0f) - ious * ious;
+    D4 l = dlog(ious);
+    return mk(0.0f) - l;
+}
+// giou_loss, iou_loss.py:103-120 (bbox_overlaps mode 'giou', iou2d_calculator.py:248-259)
+__device__ D4 giou(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float tx2f, float ty2f, float eps) {
+    const D4 tx1 = mk(tx1f), ty1 = mk(ty1f), tx2 = mk(tx2f), ty2 = mk(ty2f);
+    D4 uni;
+    const D4 ious = aligned_iou(px1, py1, px2, py2, tx1, ty1, tx2, ty2, eps, &uni);
+    const D4 ew = dclamp0(dmax(px2, tx2) - dmin(px1, tx1)), eh = dclamp0(dmax(py2, ty2) - dmin(py1, ty1));
+    const D4 ea = dmax(ew * eh, mk(eps));
+    const D4 gious = ious - (ea - uni) / ea;
+    return mk(1.0f) - gious;
+}
+// ciou_loss, iou_loss.py:230-293 (alpha is computed under torch.no_grad)
+__device__ D4 ciou(D4 px1, D4 py1, D4 px2, D4 py2, float tx1f, float ty1f, float tx2f, float ty2f, float eps) {
+    const D4 tx1 = mk(tx1f), ty1 = mk(ty1f), tx2 = mk(tx2f), ty2 = mk(ty2f);
+    const D4 w = dclamp0(dmin(px2, tx2) - dmax(px1, tx1));
+    const D4 h = dclamp0(dmin(py2, ty2) - dmax(py1, ty1));
+    const D4 overlap = w * h;
+    const D4 ap = (px2 - px1) * (py2 - py1), ag = (tx2 - tx1) * (ty2 - ty1);
+    const D4 uni = dadd((ap + ag) - overlap, eps);
+    const D4 ious = overlap / uni;
+    const D4 cw = dclamp0(dmax(px2, tx2) - dmin(px1, tx1)), ch = dclamp0(dmax(py2, ty2) - dmin(py1, ty1));
+    const D4 c2 = dadd(cw * cw + ch * ch, eps);
+    const D4 w1 = px2 - px1, h1 = dadd(py2 - py1, eps);
+    const D4 w2 = tx2 - tx1, h2 = dadd(ty2 - ty1, eps);
+    const D4 a = (tx1 + tx2) - (px1 + px2), b = (ty1 + ty2) - (py1 + py2);
+    const D4 rho2 = dscale(a * a, 0.25f) + dscale(b * b, 0.25f);
+    const D4 da = datan(w2 / h2) - datan(w1 / h1);
+    const D4 v = dscale(da * da, 0.40528473456935109f);          // 4 / pi^2
+    const float alpha = ious.v > 0.5f ? v.v / ((1.0f - ious.v) + v.v) : 0.0f;
+    const D4 cious = ious - (rho2 / c2 + dscale(v, alpha));
+    if (cious.v < -1.0f) return mk(2.0f);                       // 1 - clamp(cious, -1, 1): constant outside the range
+    if (cious.v > 1.0f) return mk(0.0f);
+    return mk(1.0f) - cious;
+}
+
 // log_sigmoid(x) = min(x,0) - log1p(exp(-|x|));  BCEWithLogits = (1-t)*x - log_sigmoid(x)
 __device__ __forceinline__ float bce_logits(float x, float t) {
     const float ls = fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
@@ -551,9 +622,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(
             const D4 hx = dscale(bw, 0.5f), hy = dscale(bh, 0.5f);   // w/2 is exact
             const D4 x1 = cx - hx, y1 = cy - hy, x2 = cx + hx, y2 = cy + hy;
             const float* tb = gt_boxes + ((size_t)n * Gmax + g) * 4;
-            D4 lb = cfg.box_loss == YUNET_BOX_EIOU
-                        ? eiou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.smooth_point, cfg.box_eps)
-                        : diou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps);
+            D4 lb;
+            switch (cfg.box_loss) {      // uniform over the launch
+                case YUNET_BOX_EIOU: lb = eiou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.smooth_point, cfg.box_eps); break;
+                case YUNET_BOX_DIOU: lb = diou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps); break;
+                case YUNET_BOX_GIOU: lb = giou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps); break;
+                case YUNET_BOX_CIOU: lb = ciou(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_eps); break;
+                default: lb = iou_family(x1, y1, x2, y2, tb[0], tb[1], tb[2], tb[3], cfg.box_loss - YUNET_BOX_IOU_LINEAR, cfg.box_eps);
+            }
             acc[1] += lb.v;
             // (d * w) * 1/num_total, in this order: with the deferred normaliser the last factor is applied by the head
             // backward (dy_scale) and the product must round the same way

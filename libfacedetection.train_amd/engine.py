@@ -371,7 +371,9 @@ class Plan:
         op.lv = self.levels
         op.loss = K.make_loss_cfg(arch['loss_bbox'], arch['loss_cls_weight'],
                                   arch['loss_bbox_weight'], arch['loss_obj_weight'],
-                                  arch['loss_kps_weight'], 1e-6, 0.1, arch['kps_beta'])
+                                  arch['loss_kps_weight'], float(arch.get('loss_bbox_eps', 1e-6)),
+                                  float(arch.get('loss_bbox_smooth_point', 0.1)), arch['kps_beta'],
+                                  arch.get('loss_bbox_mode'))
         self.fwd_b.append(op)
         self.fwd_b.append(self._op(L.OP_LOSS_FINALIZE, p=[self.loss_partials.data_ptr(),
                                                          self.losses.data_ptr(),

@@ -311,10 +311,24 @@ def nms(boxes, scores, iou_thr=0.45, score_thr=float('-inf'), max_out=None, coun
     return dets, keep, count
 
 
+def box_loss_code(box_loss, mode=None):
+    """YUNET_BOX_* of a loss class name of mmdet/models/losses/iou_loss.py (+ IoULoss's `mode`)."""
+    if box_loss == 'IoULoss':
+        try:
+            return {'linear': L.BOX_IOU_LINEAR, 'square': L.BOX_IOU_SQUARE, 'log': L.BOX_IOU_LOG}[mode or 'log']
+        except KeyError:
+            raise ValueError(f"IoULoss mode {mode!r}: 'linear', 'square' or 'log'") from None
+    table = {'EIoULoss': L.BOX_EIOU, 'DIoULoss': L.BOX_DIOU, 'GIoULoss': L.BOX_GIOU, 'CIoULoss': L.BOX_CIOU}
+    if box_loss not in table:
+        raise NotImplementedError(f'loss_bbox type {box_loss!r}: the fused loss kernel implements IoULoss, GIoULoss, '
+                                  f'DIoULoss, CIoULoss and EIoULoss (BoundedIoULoss is a smooth-L1 on box deltas)')
+    return table[box_loss]
+
+
 def make_loss_cfg(box_loss='EIoULoss', w_cls=1.0, w_box=5.0, w_obj=1.0, w_kps=0.1,
-                  box_eps=1e-6, smooth_point=0.1, kps_beta=1.0 / 9.0):
+                  box_eps=1e-6, smooth_point=0.1, kps_beta=1.0 / 9.0, box_mode=None):
     c = L.YunetLossCfg()
-    c.box_loss = {'EIoULoss': L.BOX_EIOU, 'DIoULoss': L.BOX_DIOU}[box_loss]
+    c.box_loss = box_loss_code(box_loss, box_mode)
     c.w_cls, c.w_box, c.w_obj, c.w_kps = w_cls, w_box, w_obj, w_kps
     c.box_eps, c.smooth_point, c.kps_beta = box_eps, smooth_point, kps_beta
     return c

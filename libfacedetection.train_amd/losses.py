@@ -133,6 +133,68 @@ class DIoULoss(_IoUFamily):
         return 1 - (iou - (dx ** 2 / 4 + dy ** 2 / 4) / diag2)
 
 
+def _aligned_iou(pred, target, eps):
+    """bbox_overlaps(pred, target, is_aligned=True, eps) (iou2d_calculator.py:214-246) -> (ious, union, overlap)."""
+    wh = (torch.minimum(pred[:, 2:], target[:, 2:]) - torch.maximum(pred[:, :2], target[:, :2])).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    area_p = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    area_t = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = torch.max(area_p + area_t - overlap, overlap.new_tensor([eps]))
+    return overlap / union, union, overlap
+
+
+@LOSSES.register_module()
+class IoULoss(_IoUFamily):
+    """iou_loss.py:14-50, 296-371: 1 - IoU ('linear'), 1 - IoU^2 ('square', YuNet_Head's own default,
+    yunet_head.py:59-64) or -log IoU ('log', the class default); `eps` clamps the IoU from below."""
+
+    def __init__(self, linear=False, eps=1e-6, reduction='mean', loss_weight=1.0, mode='log'):
+        super().__init__(eps, reduction, loss_weight)
+        if mode not in ('linear', 'square', 'log'):
+            raise AssertionError(mode)
+        self.mode = 'linear' if linear else mode
+        self.linear = linear
+
+    def elementwise(self, pred, target):
+        ious = _aligned_iou(pred, target, 1e-6)[0].clamp(min=self.eps)
+        if self.mode == 'linear':
+            return 1 - ious
+        return 1 - ious ** 2 if self.mode == 'square' else -ious.log()
+
+
+@LOSSES.register_module()
+class GIoULoss(_IoUFamily):
+    def elementwise(self, pred, target):
+        """Generalised IoU (iou_loss.py:103-120; iou2d_calculator.py:248-259): IoU - (enclosing - union) / enclosing."""
+        ious, union, _ = _aligned_iou(pred, target, self.eps)
+        enc = (torch.maximum(pred[:, 2:], target[:, 2:]) - torch.minimum(pred[:, :2], target[:, :2])).clamp(min=0)
+        area = torch.max(enc[:, 0] * enc[:, 1], enc.new_tensor([self.eps]))
+        return 1 - (ious - (area - union) / area)
+
+
+@LOSSES.register_module()
+class CIoULoss(_IoUFamily):
+    def elementwise(self, pred, target):
+        """Complete IoU (iou_loss.py:230-293): DIoU + alpha * v with the aspect-ratio term v; alpha carries no gradient."""
+        import math
+        eps = self.eps
+        wh = (torch.minimum(pred[:, 2:], target[:, 2:]) - torch.maximum(pred[:, :2], target[:, :2])).clamp(min=0)
+        overlap = wh[:, 0] * wh[:, 1]
+        ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+        ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+        ious = overlap / (ap + ag - overlap + eps)
+        enc = (torch.maximum(pred[:, 2:], target[:, 2:]) - torch.minimum(pred[:, :2], target[:, :2])).clamp(min=0)
+        c2 = enc[:, 0] ** 2 + enc[:, 1] ** 2 + eps
+        w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+        w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+        rho2 = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4 + \
+            ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+        v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+        with torch.no_grad():
+            alpha = (ious > 0.5).float() * v / (1 - ious + v)
+        return 1 - (ious - (rho2 / c2 + alpha * v)).clamp(min=-1.0, max=1.0)
+
+
 @LOSSES.register_module()
 class SmoothL1Loss(_FusedLoss):
     def __init__(self, beta=1.0, reduction='mean', loss_weight=1.0):

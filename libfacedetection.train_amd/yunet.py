@@ -240,6 +240,8 @@ class YuNet(nn.Module):
             feat_channels=hd.feat_channels, shared_stacked_convs=hd.shared_stack_convs,
             stacked_convs=hd.stacked_convs, kps_num=hd.NK, strides=hd.strides,
             loss_bbox=type(hd.loss_bbox).__name__, loss_bbox_weight=hd.loss_bbox.loss_weight,
+            loss_bbox_eps=hd.loss_bbox.eps, loss_bbox_smooth_point=getattr(hd.loss_bbox, 'smooth_point', 0.1),
+            loss_bbox_mode=getattr(hd.loss_bbox, 'mode', None),
             loss_cls_weight=hd.loss_cls.loss_weight, loss_obj_weight=hd.loss_obj.loss_weight,
             loss_kps_weight=hd.loss_kps.loss_weight, kps_beta=hd.loss_kps.beta,
             center_radius=hd.assigner.center_radius if hd.assigner is not None else 2.5,

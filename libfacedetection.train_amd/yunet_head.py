@@ -67,7 +67,7 @@ class YuNet_Head(nn.Module):
                  stacked_convs=2,
                  loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='sum',
                                loss_weight=1.0),
-                 loss_bbox=dict(type='EIoULoss', reduction='sum', loss_weight=5.0),
+                 loss_bbox=dict(type='IoULoss', mode='square', eps=1e-16, reduction='sum', loss_weight=5.0),
                  use_kps=False, kps_num=5, loss_kps=None, prior_generator=None, train_cfg=None,
                  test_cfg=None,
                  loss_obj=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='sum',
@@ -163,7 +163,7 @@ class YuNet_Head(nn.Module):
         return K.make_loss_cfg(box, self.loss_cls.loss_weight, self.loss_bbox.loss_weight,
                                self.loss_obj.loss_weight, self.loss_kps.loss_weight,
                                self.loss_bbox.eps, getattr(self.loss_bbox, 'smooth_point', 0.1),
-                               self.loss_kps.beta)
+                               self.loss_kps.beta, getattr(self.loss_bbox, 'mode', None))
 
     def loss(self, cls_scores, bbox_preds, objectnesses, kps_preds, gt_bboxes, gt_labels,
              gt_kpss, img_metas, gt_bboxes_ignore=None):

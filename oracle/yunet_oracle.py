@@ -47,6 +47,9 @@ def arch_from_model_cfg(model_cfg):
         strides=list(hd['prior_generator']['strides']),
         loss_bbox=hd['loss_bbox']['type'],
         loss_bbox_weight=hd['loss_bbox'].get('loss_weight', 1.0),
+        loss_bbox_eps=hd['loss_bbox'].get('eps', 1e-6),
+        loss_bbox_mode='linear' if hd['loss_bbox'].get('linear') else hd['loss_bbox'].get('mode', 'log' if hd['loss_bbox']['type'] == 'IoULoss' else None),
+        loss_bbox_smooth_point=hd['loss_bbox'].get('smooth_point', 0.1),
         loss_cls_weight=hd['loss_cls'].get('loss_weight', 1.0),
         loss_obj_weight=hd['loss_obj'].get('loss_weight', 1.0),
         loss_kps_weight=hd['loss_kps'].get('loss_weight', 1.0),
@@ -58,8 +61,9 @@ def arch_from_model_cfg(model_cfg):
     )
 
 
-def yunet_arch(kind='n', loss_bbox='EIoULoss'):
-    """The two shipped architectures (configs/yunet_n.py:104-138, yunet_s.py:108,117)."""
+def yunet_arch(kind='n', loss_bbox='EIoULoss', loss_bbox_mode=None, loss_bbox_eps=1e-6, stacked_convs=0, shared_stacked_convs=None):
+    """The two shipped architectures (configs/yunet_n.py:104-138, yunet_s.py:108,117); the keyword arguments select
+    the head variations outside the shipped parameter point (other box losses, per-level cls / reg towers)."""
     if kind == 'n':
         stages = [[3, 16, 16], [16, 64], [64, 64], [64, 64], [64, 64], [64, 64]]
         shared = 1
@@ -68,10 +72,15 @@ def yunet_arch(kind='n', loss_bbox='EIoULoss'):
         shared = 0
     else:
         raise ValueError(kind)
+    if shared_stacked_convs is not None:
+        shared = shared_stacked_convs
+    if loss_bbox == 'IoULoss' and loss_bbox_mode is None:
+        loss_bbox_mode = 'log'
     return dict(stage_channels=stages, downsample_idx=[0, 2, 3, 4], out_idx=[3, 4, 5],
                 neck_channels=[64, 64, 64], neck_out_idx=[0, 1, 2], feat_channels=64,
-                shared_stacked_convs=shared, stacked_convs=0, kps_num=5,
+                shared_stacked_convs=shared, stacked_convs=stacked_convs, kps_num=5,
                 strides=[8, 16, 32], loss_bbox=loss_bbox, loss_bbox_weight=5.0,
+                loss_bbox_eps=loss_bbox_eps, loss_bbox_mode=loss_bbox_mode, loss_bbox_smooth_point=0.1,
                 loss_cls_weight=1.0, loss_obj_weight=1.0, loss_kps_weight=0.1,
                 kps_beta=0.1111111111111111, center_radius=2.5, candidate_topk=10, iou_weight=3.0, cls_weight=1.0)
 
@@ -388,6 +397,83 @@ def smooth_l1(pred, target, beta):
     return torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
 
 
+def aligned_iou(pred, target, eps=1e-6):
+    """bbox_overlaps(pred, target, is_aligned=True, eps) (iou2d_calculator.py:214-246, 250-253) -> (ious, union)."""
+    lt = torch.max(pred[:, :2], target[:, :2])
+    rb = torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    area1 = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    area2 = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    union = area1 + area2 - overlap
+    union = torch.max(union, union.new_tensor([eps]))
+    return overlap / union, union
+
+
+def iou_loss(pred, target, mode='log', eps=1e-6):
+    """iou_loss (mmdet/models/losses/iou_loss.py:14-50): the IoU of bbox_overlaps (its own eps 1e-6) clamped from below
+    at the loss's eps, then 1 - iou | 1 - iou^2 | -log iou."""
+    ious = aligned_iou(pred, target)[0].clamp(min=eps)
+    if mode == 'linear':
+        return 1 - ious
+    if mode == 'square':
+        return 1 - ious ** 2
+    assert mode == 'log', mode
+    return -ious.log()
+
+
+def giou_loss(pred, target, eps=1e-6):
+    """giou_loss (iou_loss.py:103-120) = 1 - bbox_overlaps(mode='giou', eps) (iou2d_calculator.py:248-259); the class
+    default eps is 1e-6 (iou_loss.py:377)."""
+    ious, union = aligned_iou(pred, target, eps)
+    e1 = torch.min(pred[:, :2], target[:, :2])
+    e2 = torch.max(pred[:, 2:], target[:, 2:])
+    ewh = (e2 - e1).clamp(min=0)
+    area = torch.max(ewh[:, 0] * ewh[:, 1], ewh.new_tensor([eps]))
+    return 1 - (ious - (area - union) / area)
+
+
+def ciou_loss(pred, target, eps=1e-6):
+    """ciou_loss (iou_loss.py:230-293); class default eps 1e-6 (:498)."""
+    lt = torch.max(pred[:, :2], target[:, :2])
+    rb = torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    ious = overlap / (ap + ag - overlap + eps)
+    e1 = torch.min(pred[:, :2], target[:, :2])
+    e2 = torch.max(pred[:, 2:], target[:, 2:])
+    ewh = (e2 - e1).clamp(min=0)
+    c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + eps
+    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+    left = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4
+    right = ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+    rho2 = left + right
+    v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    with torch.no_grad():
+        alpha = (ious > 0.5).float() * v / (1 - ious + v)
+    cious = ious - (rho2 / c2 + alpha * v)
+    return 1 - cious.clamp(min=-1.0, max=1.0)
+
+
+def box_loss_fn(arch):
+    """The elementwise box loss named by the head config (mmdet/models/losses/iou_loss.py)."""
+    kind, eps = arch['loss_bbox'], float(arch.get('loss_bbox_eps', 1e-6))
+    if kind == 'EIoULoss':
+        return lambda p, t: eiou_loss(p, t, float(arch.get('loss_bbox_smooth_point', 0.1)), eps)
+    if kind == 'DIoULoss':
+        return lambda p, t: diou_loss(p, t, eps)
+    if kind == 'IoULoss':
+        return lambda p, t: iou_loss(p, t, arch.get('loss_bbox_mode') or 'log', eps)
+    if kind == 'GIoULoss':
+        return lambda p, t: giou_loss(p, t, eps)
+    if kind == 'CIoULoss':
+        return lambda p, t: ciou_loss(p, t, eps)
+    raise NotImplementedError(kind)
+
+
 def loss_step(flat, gt_bboxes, gt_labels, gt_kpss, featmap_sizes, arch, world_mean_num_pos=None):
     """YuNet_Head.loss on flattened predictions (yunet_head.py:418-534) with
     _get_target_single (:536-604), PseudoSampler (samplers/pseudo_sampler.py:24-42).
@@ -430,7 +516,7 @@ def loss_step(flat, gt_bboxes, gt_labels, gt_kpss, featmap_sizes, arch, world_me
     num_total = max(n_pos, torch.tensor(1.0))
     obj_t = pos_mask.float()
 
-    box_fn = eiou_loss if arch['loss_bbox'] == 'EIoULoss' else diou_loss
+    box_fn = box_loss_fn(arch)
     l_box = arch['loss_bbox_weight'] * box_fn(decoded.reshape(-1, 4)[pos_mask], box_t).sum() \
         / num_total
     l_obj = arch['loss_obj_weight'] * F.binary_cross_entropy_with_logits(

@@ -40,7 +40,14 @@ def test_against_reference_classes():
     w1, w4 = torch.rand(64, generator=g), torch.rand(64, 4, generator=g)
     pairs = [(L.EIoULoss(loss_weight=5.0, reduction='sum'), ns.losses.iou.EIoULoss(loss_weight=5.0, reduction='sum')),
              (L.EIoULoss(reduction='mean'), ns.losses.iou.EIoULoss(reduction='mean')),
-             (L.DIoULoss(loss_weight=2.0, reduction='sum'), ns.losses.iou.DIoULoss(loss_weight=2.0, reduction='sum'))]
+             (L.DIoULoss(loss_weight=2.0, reduction='sum'), ns.losses.iou.DIoULoss(loss_weight=2.0, reduction='sum')),
+             # round 5: the rest of the family (YuNet_Head's own default is IoULoss(mode='square', eps=1e-16))
+             (L.IoULoss(mode='square', eps=1e-16, reduction='sum', loss_weight=5.0),
+              ns.losses.iou.IoULoss(mode='square', eps=1e-16, reduction='sum', loss_weight=5.0)),
+             (L.IoULoss(mode='linear'), ns.losses.iou.IoULoss(mode='linear')),
+             (L.IoULoss(), ns.losses.iou.IoULoss()),
+             (L.GIoULoss(reduction='sum'), ns.losses.iou.GIoULoss(reduction='sum')),
+             (L.CIoULoss(reduction='sum', loss_weight=2.0), ns.losses.iou.CIoULoss(reduction='sum', loss_weight=2.0))]
     cases = [dict(), dict(weight=w1), dict(weight=w4), dict(reduction_override='none'),
              dict(weight=w1, avg_factor=7.0, reduction_override='mean'), dict(weight=torch.zeros(64))]
     for mine, ref in pairs:

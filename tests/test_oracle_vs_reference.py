@@ -52,10 +52,10 @@ def test_reference_config_and_checkpoint_load_in_the_new_framework():
         assert list(m.state_dict().keys()) == list(ref_model.state_dict().keys())
 
 
-def _ref_and_oracle_loss_step(flat, gb, gl, gk, h, loss_bbox):
+def _ref_and_oracle_loss_step(flat, gb, gl, gk, h, loss_bbox, **box_kw):
     import make_golden as MG
     sizes = C.featmap_sizes(h, h)
-    model, _ = ref_stub.build_detector('yunet_n.py', loss_bbox=dict(type=loss_bbox, loss_weight=5.0, reduction='sum'))
+    model, _ = ref_stub.build_detector('yunet_n.py', loss_bbox=dict(type=loss_bbox, loss_weight=5.0, reduction='sum', **box_kw))
     head = model.bbox_head
     rec = MG.AssignRecorder(head.assigner)
     head.assigner = rec
@@ -65,7 +65,7 @@ def _ref_and_oracle_loss_step(flat, gb, gl, gk, h, loss_bbox):
     sum(losses.values()).backward()
     gi_ref = torch.stack([r[0] for r in rec.records])
     fo = flat.clone().requires_grad_(True)
-    lo, aux = O.loss_step(fo, gb, gl, gk, sizes, O.yunet_arch('n', loss_bbox))
+    lo, aux = O.loss_step(fo, gb, gl, gk, sizes, O.yunet_arch('n', loss_bbox, box_kw.get('mode'), box_kw.get('eps', 1e-6)))
     sum(lo.values()).backward()
     return losses, fr.grad, gi_ref, lo, fo.grad, aux['gt_inds']
 
@@ -147,4 +147,23 @@ def test_crowded_loss_step_matches_live_reference(h, counts, seed, loss_bbox):
     assert torch.equal(gi_ref2, gi_o2)
     for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
         assert abs(float(losses[k]) - float(lo[k])) <= 1e-6 * abs(float(lo[k])) + 1e-7, k
+    assert float((g_ref - g_o).abs().max()) <= 1e-5 * float(g_ref.abs().max())
+
+
+@pytest.mark.parametrize('loss_bbox,kw', [('IoULoss', dict(mode='square', eps=1e-16)),      # YuNet_Head's own default (yunet_head.py:59-64)
+                                          ('IoULoss', dict(mode='linear')), ('IoULoss', dict(mode='log')),
+                                          ('GIoULoss', dict()), ('CIoULoss', dict())])
+def test_other_box_losses_match_live_reference(loss_bbox, kw):
+    """The rest of the reference's IoU-loss family through the UNMODIFIED YuNet_Head.loss (round 5: the head builds with
+    its own default loss_bbox, and with GIoULoss / CIoULoss): losses 1e-6, d loss / d flat 1e-5 of scale, assignment equal."""
+    import yunet_amd.synthetic as S
+    h = 320
+    b = S.make_batch(6, h, h, 101, with_img=False)          # (a tie-free seed: torch.topk leaves equal costs unordered)
+    flat = C.crafted_preds(b['gt_bboxes'], b['gt_keypointss'], h, h, 102)
+    losses, g_ref, gi_ref, lo, g_o, gi_o = _ref_and_oracle_loss_step(flat, list(b['gt_bboxes']), b['gt_labels'],
+                                                                      list(b['gt_keypointss']), h, loss_bbox, **kw)
+    assert torch.equal(gi_ref, gi_o)
+    for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
+        assert abs(float(losses[k]) - float(lo[k])) <= 1e-6 * abs(float(lo[k])) + 1e-7, (k, float(losses[k]), float(lo[k]))
+    assert float(lo['loss_bbox']) > 0
     assert float((g_ref - g_o).abs().max()) <= 1e-5 * float(g_ref.abs().max())
