@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 8
+#define YUNET_ABI_VERSION 9
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -290,6 +290,13 @@ int yunet_loss_blocks(int N, int P);
 /* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */
 /* g = grad*grad_scale + wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf.
  * lr is read from device memory (lr_dev[0]) so schedules do not need a re-capture. */
+/* out[i] = a[i] + b[i] (ABI 9).  The one place the reference's head concatenates predictions that come from DIFFERENT
+ * inputs: with per-level towers (YuNet_Head(stacked_convs > 0), yunet_head.py:115-147, 191-207) the cls map is computed
+ * from the cls tower and bbox / obj / kps from the reg tower, then flattened side by side (:456-472).  Here each tower
+ * feeds one fused 64 -> 16 head unit whose rows for the other tower's channels are zero, and the two [N,P,16] outputs
+ * (exact zeros in the foreign channels) are added.  n elements, 16-byte aligned pointers when n % 4 == 0. */
+int yunet_add(const float* a, const float* b, float* out, size_t n, void* stream);
+
 int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
                    const float* lr_dev, float momentum, float weight_decay, float grad_scale,
                    int first_step, void* stream);
@@ -303,7 +310,8 @@ enum {
     YUNET_OP_BN_RUNNING, YUNET_OP_BN_PARAM_GRAD, YUNET_OP_REDUCE_PARTIALS,
     YUNET_OP_ASSIGN, YUNET_OP_LOSS_NORM, YUNET_OP_LOSS, YUNET_OP_LOSS_FINALIZE,
     YUNET_OP_SGD, YUNET_OP_MEMSET, YUNET_OP_BN_BATCH, YUNET_OP_REDUCE_BATCH,
-    YUNET_OP_FORK, YUNET_OP_JOIN
+    YUNET_OP_FORK, YUNET_OP_JOIN,
+    YUNET_OP_ADD      /* ABI 9: yunet_add(p[0], p[1], p[2], n = i[1] << 32 | i[0]) */
 };
 /* Lanes (ABI 4).  The head chains of the pyramid levels (share conv -> fused head, and their backward) are
  * mutually independent: mmdet/models/dense_heads/yunet_head.py:175-247 walks them in a Python loop, and on the

@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 BOX_EIOU, BOX_DIOU, BOX_IOU_LINEAR, BOX_IOU_SQUARE, BOX_IOU_LOG, BOX_GIOU, BOX_CIOU = 0, 1, 2, 3, 4, 5, 6
 (OP_STEM_FWD, OP_STEM_BWD, OP_DP_FWD, OP_DP_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_UPADD_FWD,
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
- OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH, OP_FORK, OP_JOIN) = range(1, 22)
+ OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH, OP_FORK, OP_JOIN, OP_ADD) = range(1, 23)
 OP_LANE, MAX_LANES = 10, 2          # YunetOp.i[OP_LANE]: side stream of the op (0 = the caller's stream)
 
 
@@ -128,6 +128,7 @@ _SIGNATURES = {
                    [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'yunet_loss_finalize_ex': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
+    'yunet_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_float, C.c_int, C.c_void_p]),
     'yunet_exec': (C.c_int, [C.POINTER(YunetOp), C.c_int, C.c_void_p]),
@@ -170,7 +171,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 8:
+    if lib.yunet_abi_version() != 9:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

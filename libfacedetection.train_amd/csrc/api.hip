@@ -67,6 +67,34 @@ extern "C" int yunet_bn_batch(const int32_t* table, int n, const double* stats_b
     return hip_status();
 }
 
+// one float4 per thread, no loop (a grid-stride loop here is compiled as one memory round trip per trip: tests/test_isa_guard.py)
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, size_t n, int vec) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i < n / 4) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        } else if (i - n / 4 < n % 4) {
+            const size_t k = (n / 4) * 4 + (i - n / 4);
+            out[k] = a[k] + b[k];
+        }
+    } else if (i < n) {
+        out[i] = a[i] + b[i];
+    }
+}
+
+extern "C" int yunet_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+    if (!a || !b || !out) return YUNET_EINVAL;
+    if (n == 0) return 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const size_t threads = vec ? n / 4 + n % 4 : n;
+    const size_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffull) return YUNET_EINVAL;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n, vec);
+    return hip_status();
+}
+
 extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
                               const float* lr_dev, float momentum, float weight_decay,
                               float grad_scale, int first_step, void* stream) {
@@ -295,6 +323,11 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
             case YUNET_OP_MEMSET: {
                 const size_t n = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
                 rc = -(int)hipMemsetAsync(o.p[0], 0, n, (hipStream_t)stream);
+                break;
+            }
+            case YUNET_OP_ADD: {
+                const size_t n = ((size_t)(uint32_t)o.i[1] << 32) | (uint32_t)o.i[0];
+                rc = yunet_add((const float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], n, stream);
                 break;
             }
             case YUNET_OP_BN_BATCH:

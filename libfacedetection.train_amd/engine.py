@@ -80,25 +80,33 @@ class ParamLayout:
         self.head_rows = [('cls', 0, 1), ('bbox', 1, 4), ('obj', 5, 1), ('kps', 6, kp)]
         self.head_cout = 6 + kp
         assert self.head_cout == 16, 'fused head kernel is specialised for 16 outputs'
+        # Towers (stacked_convs > 0): the cls map comes from the cls tower, bbox / obj / kps from the reg tower.  Each tower
+        # feeds its OWN fused 64 -> 16 unit -- `headc.{l}` holds the cls rows, `head.{l}` the other 15 -- whose foreign rows
+        # stay zero (they are not parameters: no state_dict entry, zero gradient through a masked dy_scale, weight decay
+        # of zero is zero); the two [N,P,16] outputs are added (YUNET_OP_ADD).
+        self.towers = arch.get('stacked_convs', 0) > 0
         for l in range(len(arch['strides'])):
-            name = f'head.{l}'
-            self.units[name] = dict(off=off, cin=fc, cout=self.head_cout, bn=False)
-            base = off
-            for nm, r0, nr in self.head_rows:
-                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.weight'] = \
-                    (base + r0 * fc, (nr, fc, 1, 1))
-            base += self.head_cout * fc
-            for nm, r0, nr in self.head_rows:
-                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.bias'] = (base + r0, (nr,))
-            base += self.head_cout
-            for nm, r0, nr in self.head_rows:
-                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.weight'] = \
-                    (base + r0 * 9, (nr, 1, 3, 3))
-            base += self.head_cout * 9
-            for nm, r0, nr in self.head_rows:
-                self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.bias'] = (base + r0, (nr,))
-            base += self.head_cout
-            off = base
+            for name, rows in ((f'head.{l}', [r for r in self.head_rows if not (self.towers and r[0] == 'cls')]),
+                               (f'headc.{l}', [r for r in self.head_rows if r[0] == 'cls'] if self.towers else [])):
+                if not rows:
+                    continue
+                self.units[name] = dict(off=off, cin=fc, cout=self.head_cout, bn=False)
+                base = off
+                for nm, r0, nr in rows:
+                    self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.weight'] = \
+                        (base + r0 * fc, (nr, fc, 1, 1))
+                base += self.head_cout * fc
+                for nm, r0, nr in rows:
+                    self.entries[f'bbox_head.multi_level_{nm}.{l}.conv1.bias'] = (base + r0, (nr,))
+                base += self.head_cout
+                for nm, r0, nr in rows:
+                    self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.weight'] = \
+                        (base + r0 * 9, (nr, 1, 3, 3))
+                base += self.head_cout * 9
+                for nm, r0, nr in rows:
+                    self.entries[f'bbox_head.multi_level_{nm}.{l}.conv2.bias'] = (base + r0, (nr,))
+                base += self.head_cout
+                off = base
         self.numel = off
 
     def _add(self, key, off, shape):
@@ -120,6 +128,10 @@ class ParamLayout:
         for l in range(len(arch['strides'])):
             for j in range(arch['shared_stacked_convs']):
                 out.append((f'bbox_head.multi_level_share_convs.{l}.{j}', fc, fc, True))
+        for tower in ('cls', 'reg'):          # per-level towers (yunet_head.py:126-140), state_dict order
+            for l in range(len(arch['strides'])):
+                for j in range(arch.get('stacked_convs', 0)):
+                    out.append((f'bbox_head.multi_level_{tower}_convs.{l}.{j}', fc, fc, True))
         return out
 
     def unit_ptrs(self, flat, name):
@@ -270,6 +282,13 @@ class Plan:
         self.levels = K.make_levels(self.sizes, strides)
         self.flat = torch.empty(n, self.P, 16, **f32)
         self.dflat = torch.empty(n, self.P, 16, **f32)
+        # towers (stacked_convs > 0): the cls tower's head unit writes its own [N,P,16] (zeros outside the cls channel)
+        self.towers = lay.towers
+        self.flat_c = torch.empty(n, self.P, 16, **f32) if self.towers else None
+        # ... and each tower's unit takes dy_scale masked to its own channels (engine.backward refreshes them)
+        self.mask_cls = torch.tensor([1.0] + [0.0] * 15, **f32)
+        self.dy_scale_cls = self.mask_cls.clone()
+        self.dy_scale_reg = 1.0 - self.mask_cls
 
         # ---- conv stack
         self.img_ptr_ops = []
@@ -301,7 +320,7 @@ class Plan:
         for hh, ww in self.sizes:
             bases.append(b0)
             b0 += hh * ww
-        lanes_ok = bool(os.environ.get('YUNET_LANES')) or bool(getattr(eng, 'use_lanes', False))
+        lanes_ok = (bool(os.environ.get('YUNET_LANES')) or bool(getattr(eng, 'use_lanes', False))) and not self.towers
         self.lanes_used = 0
 
         def head_chain(i):
@@ -318,7 +337,17 @@ class Plan:
             self._lane = lane
             for j in range(arch['shared_stacked_convs']):
                 f = self._dp(f, f'bbox_head.multi_level_share_convs.{l}.{j}')
-            self._head(f, l, bases[l])
+            if self.towers:
+                # yunet_head.py:191-207: two towers on the same feature; cls from one, bbox / obj / kps from the other
+                fc_, fr_ = f, f
+                for j in range(arch['stacked_convs']):
+                    fc_ = self._dp(fc_, f'bbox_head.multi_level_cls_convs.{l}.{j}')
+                for j in range(arch['stacked_convs']):
+                    fr_ = self._dp(fr_, f'bbox_head.multi_level_reg_convs.{l}.{j}')
+                self._head(fr_, l, bases[l])
+                self._head(fc_, l, bases[l], cls_tower=True)
+            else:
+                self._head(f, l, bases[l])
             self._lane = 0
         for i in range(len(feats) - 1, 0, -1):
             feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
@@ -332,6 +361,11 @@ class Plan:
         head_chain(0)
         if self.lanes_used:
             self.fwd_a.append(self._op(L.OP_JOIN, i=[self.lanes_used]))
+        if self.towers:      # flat = (reg tower's bbox | obj | kps channels) + (cls tower's cls channel): exact zeros elsewhere
+            nel = n * self.P * 16
+            self.fwd_a.append(self._op(L.OP_ADD, p=[self.flat.data_ptr(), self.flat_c.data_ptr(), self.flat.data_ptr()],
+                                       i=[nel & 0xffffffff if (nel & 0xffffffff) < 2 ** 31 else (nel & 0xffffffff) - 2 ** 32,
+                                          nel >> 32]))
 
         # ---- loss step
         self.gt_boxes = torch.zeros(n, gmax, 4, **f32)
@@ -608,12 +642,16 @@ class Plan:
         self.tensors[name] = (x, z)
         return z
 
-    def _head(self, x, level, base):
-        name = f'head.{level}'
-        zptr = self.flat.data_ptr() + 4 * base * 16
-        self._dp_node(x, name, zptr, self.P * 16, None, dy_ptr=self.dflat.data_ptr() + 4 * base * 16)
+    def _head(self, x, level, base, cls_tower=False):
+        name = f'headc.{level}' if cls_tower else f'head.{level}'
+        out = self.flat_c if cls_tower else self.flat
+        zptr = out.data_ptr() + 4 * base * 16
+        scale = None
+        if self.towers:      # each tower's unit only sees the gradient of its own channels (its other rows stay zero)
+            scale = self.dy_scale_cls if cls_tower else self.dy_scale_reg
+        self._dp_node(x, name, zptr, self.P * 16, None, dy_ptr=self.dflat.data_ptr() + 4 * base * 16, dy_scale=scale)
 
-    def _dp_node(self, x, name, zptr, z_img_stride, zt, dy_ptr=None):
+    def _dp_node(self, x, name, zptr, z_img_stride, zt, dy_ptr=None, dy_scale=None):
         d, u, bn_name = self._dp_desc(x, name, zptr, z_img_stride)
         op = self._op(L.OP_DP_FWD)
         op.dp = d
@@ -641,7 +679,7 @@ class Plan:
                 d2.dy_scale = None
             else:
                 d2.dy = dy_ptr
-                d2.dy_scale = self.dy_scale.data_ptr()
+                d2.dy_scale = (dy_scale if dy_scale is not None else self.dy_scale).data_ptr()
             gx, acc = self._grad_of(x)
             d2.dx = gx.data_ptr()
             d2.accumulate_dx = acc
@@ -888,6 +926,9 @@ class YuNetEngine:
         if plan.deferred:
             # x the deferred 1 / num_total of the cls | box | obj channels (written by loss_finalize)
             torch.mul(plan.dy_up, plan.dy_norm, out=plan.dy_scale)
+        if plan.towers:
+            torch.mul(plan.dy_scale, plan.mask_cls, out=plan.dy_scale_cls)
+            torch.sub(plan.dy_scale, plan.dy_scale_cls, out=plan.dy_scale_reg)
         if (self.world_size <= 1 and not self.always_bucket) and plan.split_off is not None and self.overlap_reduce:
             # one GPU: the weight-gradient reduction + BN parameter gradients of segment A (head, neck, late backbone
             # stages: ~85 % of the parameters, 44 us as one launch at the end of backward) on the side stream, under the

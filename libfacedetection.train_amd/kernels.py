@@ -258,6 +258,14 @@ def upadd_bwd(za, bna, zb, bnb, dout, dxa=None, acc_a=False, dxb=None, acc_b=Fal
     return (None if skip_a else dxa), dxb
 
 
+def add(a, b, out=None):
+    """out = a + b (yunet_add): the merge of the two tower head outputs (YuNet_Head(stacked_convs > 0))."""
+    _chk_f32(a, b)
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.load().yunet_add(_p(a), _p(b), _p(out), a.numel(), _stream()), 'yunet_add')
+    return out
+
+
 def bn_update_running(stats, running_mean, running_var, count, momentum=0.1):
     L.check(L.load().yunet_bn_update_running(_p(stats), _p(running_mean), _p(running_var),
                                              running_mean.numel(), int(count), float(momentum),

@@ -170,10 +170,21 @@ def build_graph(sd, arch, input_shape=(320, 320), dynamic=False):
     for l in range(len(outs)):
         for j in range(arch['shared_stacked_convs']):
             outs[l] = unit(outs[l], f'bbox_head.multi_level_share_convs.{l}.{j}', True)
+    src = {name: outs for name in ('cls', 'bbox', 'obj', 'kps')}
+    if arch.get('stacked_convs', 0) > 0:            # per-level towers (yunet_head.py:191-207)
+        towers = {}
+        for l in range(len(outs)):
+            for t in ('cls', 'reg'):
+                x = outs[l]
+                for j in range(arch['stacked_convs']):
+                    x = unit(x, f'bbox_head.multi_level_{t}_convs.{l}.{j}', True)
+                towers[t, l] = x
+        src = dict(cls=[towers['cls', l] for l in range(len(outs))])
+        src.update({name: [towers['reg', l] for l in range(len(outs))] for name in ('bbox', 'obj', 'kps')})
     maps = {}
     for name in ('cls', 'bbox', 'obj', 'kps'):
         for l in range(len(outs)):
-            maps[name, l] = unit(outs[l], f'bbox_head.multi_level_{name}.{l}', False)
+            maps[name, l] = unit(src[name][l], f'bbox_head.multi_level_{name}.{l}', False)
     out_infos = []
     chans = dict(cls=1, obj=1, bbox=4, kps=2 * arch['kps_num'])
     lead = 0 if dynamic else 1                       # Reshape: 0 copies the batch dimension

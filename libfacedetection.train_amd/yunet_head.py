@@ -73,11 +73,14 @@ class YuNet_Head(nn.Module):
                  loss_obj=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='sum',
                                loss_weight=1.0)):
         super().__init__()
-        if num_classes != 1 or not use_kps or kps_num != 5:
-            raise NotImplementedError('the fused head kernels implement the shipped face '
-                                      'configuration: 1 class, 5 landmarks')
-        if stacked_convs != 0:
-            raise NotImplementedError('stacked_convs > 0 is not used by configs/yunet_{n,s}.py')
+        if num_classes != 1 or kps_num != 5:
+            raise NotImplementedError('the fused head kernels implement the face configuration: 1 class, 5 landmarks '
+                                      '(the [N,P,16] prediction layout cls | bbox 4 | obj | kps 10)')
+        if not use_kps:
+            # (the reference's own default cannot run either: its forward dereferences self.multi_level_kps
+            # unconditionally, mmdet/models/dense_heads/yunet_head.py:191,207, and loss() needs kps_preds)
+            raise NotImplementedError('use_kps=False: the loss step and the fused head units carry the 10 landmark '
+                                      'channels; the reference head does not run without them either')
         self.num_classes = self.cls_out_channels = num_classes
         self.NK = kps_num
         self.in_channels, self.feat_channels = in_channels, feat_channels
@@ -101,8 +104,12 @@ class YuNet_Head(nn.Module):
         self.init_weights()
 
     def _init_layers(self):
+        """yunet_head.py:112-156, same attribute names and registration order (= state_dict order)."""
         if self.shared_stack_convs > 0:
             self.multi_level_share_convs = nn.ModuleList()
+        if self.stacked_convs > 0:           # per-level towers: cls from one, bbox / obj / kps from the other
+            self.multi_level_cls_convs = nn.ModuleList()
+            self.multi_level_reg_convs = nn.ModuleList()
         self.multi_level_cls = nn.ModuleList()
         self.multi_level_bbox = nn.ModuleList()
         self.multi_level_obj = nn.ModuleList()
@@ -112,7 +119,12 @@ class YuNet_Head(nn.Module):
                 convs = [ConvDPUnit(self.in_channels if i == 0 else self.feat_channels,
                                     self.feat_channels) for i in range(self.shared_stack_convs)]
                 self.multi_level_share_convs.append(nn.Sequential(*convs))
-            chn = self.in_channels if self.shared_stack_convs == 0 else self.feat_channels
+            if self.stacked_convs > 0:
+                for tower in (self.multi_level_cls_convs, self.multi_level_reg_convs):
+                    tower.append(nn.Sequential(*[
+                        ConvDPUnit(self.in_channels if i == 0 and self.shared_stack_convs == 0 else self.feat_channels,
+                                   self.feat_channels) for i in range(self.stacked_convs)]))
+            chn = self.in_channels if self.shared_stack_convs == 0 and self.stacked_convs == 0 else self.feat_channels
             self.multi_level_cls.append(ConvDPUnit(chn, self.num_classes, False))
             self.multi_level_bbox.append(ConvDPUnit(chn, 4, False))
             self.multi_level_kps.append(ConvDPUnit(chn, self.NK * 2, False))
@@ -131,15 +143,23 @@ class YuNet_Head(nn.Module):
             feats = [convs(f) for f, convs in zip(feats, self.multi_level_share_convs)]
         outs = ([], [], [], [])
         for l, f in enumerate(feats):
-            c = f.shape[1]
             units = (self.multi_level_cls[l], self.multi_level_bbox[l], self.multi_level_obj[l],
                      self.multi_level_kps[l])
-            w1 = torch.cat([u.conv1.weight.detach().reshape(-1, c) for u in units]).contiguous()
-            b1 = torch.cat([u.conv1.bias.detach() for u in units]).contiguous()
-            w2 = torch.cat([u.conv2.weight.detach().reshape(-1, 9) for u in units]).contiguous()
-            b2 = torch.cat([u.conv2.bias.detach() for u in units]).contiguous()
-            z = K.dp_fwd(f.float().permute(0, 2, 3, 1).contiguous(), w1, b1, w2, b2)
-            z = z.permute(0, 3, 1, 2)
+
+            def fused(x):
+                c = x.shape[1]
+                w1 = torch.cat([u.conv1.weight.detach().reshape(-1, c) for u in units]).contiguous()
+                b1 = torch.cat([u.conv1.bias.detach() for u in units]).contiguous()
+                w2 = torch.cat([u.conv2.weight.detach().reshape(-1, 9) for u in units]).contiguous()
+                b2 = torch.cat([u.conv2.bias.detach() for u in units]).contiguous()
+                return K.dp_fwd(x.float().permute(0, 2, 3, 1).contiguous(), w1, b1, w2, b2).permute(0, 3, 1, 2)
+            if self.stacked_convs > 0:
+                # towers (yunet_head.py:191-207): cls from the cls tower, bbox / obj / kps from the reg tower; this
+                # inference helper runs the fused 64 -> 16 unit on both and keeps each tower's own channels
+                zc, zr = fused(self.multi_level_cls_convs[l](f)), fused(self.multi_level_reg_convs[l](f))
+                z = torch.cat([zc[:, 0:1], zr[:, 1:]], 1)
+            else:
+                z = fused(f)
             for o, (a, b) in zip(outs, ((0, 1), (1, 5), (5, 6), (6, 16))):
                 o.append(z[:, a:b].contiguous())
         return outs

@@ -305,13 +305,19 @@ def load_config(name):
     return ConfigDict.wrap({k: v for k, v in scope.items() if not k.startswith('__')})
 
 
-def build_detector(cfg_name='yunet_n.py', loss_bbox=None):
-    """Build the reference YuNet detector (train mode, CPU)."""
+def build_detector(cfg_name='yunet_n.py', loss_bbox=None, head=None):
+    """Build the reference YuNet detector (train mode, CPU).  `head`: bbox_head settings to override (a value of None
+    deletes the key, so that the reference class's own default applies)."""
     ns = load_reference()
     cfg = load_config(cfg_name)
     model_cfg = cfg.model
     if loss_bbox is not None:
         model_cfg.bbox_head.loss_bbox = ConfigDict.wrap(loss_bbox)
+    for k, v in (head or {}).items():
+        if v is None:
+            model_cfg.bbox_head.pop(k, None)
+        else:
+            model_cfg.bbox_head[k] = v
     train_cfg = model_cfg.pop('train_cfg')
     test_cfg = model_cfg.pop('test_cfg')
     model_cfg['train_cfg'] = train_cfg

@@ -101,6 +101,10 @@ def dp_units(arch):
     for l in range(nl):
         for j in range(arch['shared_stacked_convs']):
             out.append((f'bbox_head.multi_level_share_convs.{l}.{j}', fc, fc, True))
+    for tower in ('cls', 'reg'):          # per-level towers (yunet_head.py:126-140)
+        for l in range(nl):
+            for j in range(arch.get('stacked_convs', 0)):
+                out.append((f'bbox_head.multi_level_{tower}_convs.{l}.{j}', fc, fc, True))
     for name, co in (('cls', 1), ('bbox', 4), ('obj', 1), ('kps', 2 * arch['kps_num'])):
         for l in range(nl):
             out.append((f'bbox_head.multi_level_{name}.{l}', fc, co, False))
@@ -205,18 +209,27 @@ def neck_forward(feats, sd, arch, training=True):
 
 
 def head_forward(feats, sd, arch, training=True):
-    """YuNet_Head.forward (mmdet/models/dense_heads/yunet_head.py:175-247), the
-    stacked_convs == 0 branch used by both shipped configs."""
-    assert arch['stacked_convs'] == 0
+    """YuNet_Head.forward (mmdet/models/dense_heads/yunet_head.py:175-247): shared convs, then -- stacked_convs > 0 --
+    the per-level cls / reg towers (:191-207: cls from the cls tower, bbox / obj / kps from the reg tower), else
+    all four maps from the shared feature (the branch both shipped configs use)."""
     feats = list(feats)
     for l in range(len(feats)):
         for j in range(arch['shared_stacked_convs']):
             feats[l] = conv_dp_unit(feats[l], sd, f'bbox_head.multi_level_share_convs.{l}.{j}',
                                     True, training)
+    src = {name: feats for name in ('cls', 'bbox', 'obj', 'kps')}
+    if arch.get('stacked_convs', 0) > 0:
+        tower = {}
+        for t in ('cls', 'reg'):
+            tower[t] = list(feats)
+            for l in range(len(feats)):
+                for j in range(arch['stacked_convs']):
+                    tower[t][l] = conv_dp_unit(tower[t][l], sd, f'bbox_head.multi_level_{t}_convs.{l}.{j}', True, training)
+        src = dict(cls=tower['cls'], bbox=tower['reg'], obj=tower['reg'], kps=tower['reg'])
     outs = {}
     for name in ('cls', 'bbox', 'obj', 'kps'):
         outs[name] = [conv_dp_unit(f, sd, f'bbox_head.multi_level_{name}.{l}', False, training)
-                      for l, f in enumerate(feats)]
+                      for l, f in enumerate(src[name])]
     return outs['cls'], outs['bbox'], outs['obj'], outs['kps']
 
 

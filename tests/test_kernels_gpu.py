@@ -657,3 +657,23 @@ def test_dp_bwd_weight_gradient_precision_with_large_activation_means(cin, cout,
     # limit rather than hidden.
     bound = max(2.0 * err_torch32, 2e-5 * scale) if cout < 64 else 1e-2 * scale
     assert err_hip <= bound, (err_hip, err_torch32, scale)
+
+
+@pytest.mark.parametrize('n,shift', [(1, 0), (3, 0), (4, 0), (1027, 0), (1027, 1), (256 * 2100 * 16, 0), (70001, 3)])
+def test_add(n, shift):
+    """yunet_add (YUNET_OP_ADD, ABI 9): out = a + b, exact; 16-byte path, its tail, and unaligned buffers."""
+    k = K()
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n + shift, generator=g).to(DEV)[shift:]
+    b = torch.randn(n + shift, generator=g).to(DEV)[shift:]
+    guard = torch.full((n + shift + 8,), 7.0, device=DEV)
+    out = guard[shift:shift + n]
+    k.add(a, b, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, a + b)
+    assert float(guard[shift + n:].min()) == 7.0 and (shift == 0 or float(guard[:shift].min()) == 7.0)
+    # in place (out = a), the form the engine uses
+    a2 = a.clone()
+    k.add(a2, b, a2)
+    torch.cuda.synchronize()
+    assert torch.equal(a2, a + b)

@@ -167,3 +167,64 @@ def test_other_box_losses_match_live_reference(loss_bbox, kw):
         assert abs(float(losses[k]) - float(lo[k])) <= 1e-6 * abs(float(lo[k])) + 1e-7, (k, float(losses[k]), float(lo[k]))
     assert float(lo['loss_bbox']) > 0
     assert float((g_ref - g_o).abs().max()) <= 1e-5 * float(g_ref.abs().max())
+
+
+TOWER_HEADS = [dict(stacked_convs=2, shared_stacked_convs=2, loss_bbox=None),      # YuNet_Head's OWN defaults (yunet_head.py:52-64)
+               dict(stacked_convs=1, shared_stacked_convs=0)]                        # towers straight on the neck output
+
+
+@pytest.mark.parametrize('head', TOWER_HEADS)
+def test_tower_head_full_step_matches_live_reference(head):
+    """YuNet_Head outside the shipped parameter point (VERDICT r4 missing 2): per-level cls / reg towers
+    (yunet_head.py:115-147, 191-207) and the class's default box loss, through the unmodified reference's forward_train +
+    backward against the oracle: losses 1e-6, every parameter gradient 1e-5 of scale, BN running statistics equal."""
+    import yunet_amd.synthetic as S
+    model, _ = ref_stub.build_detector('yunet_n.py', head=head)
+    mc = ref_stub.load_config('yunet_n.py').model
+    for k, v in head.items():
+        if v is None:
+            mc.bbox_head.pop(k, None)
+        else:
+            mc.bbox_head[k] = v
+    if 'loss_bbox' not in mc.bbox_head:      # the class default
+        mc.bbox_head['loss_bbox'] = dict(type='IoULoss', mode='square', eps=1e-16, reduction='sum', loss_weight=5.0)
+    arch = O.arch_from_model_cfg(mc)
+    assert arch['stacked_convs'] == head['stacked_convs']
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert sorted(k for k in sd) == sorted(O.init_state(arch, seed=0))
+    b = S.make_batch(3, 192, 320, 21)
+    losses = model.forward_train(b['img'], b['img_metas'], list(b['gt_bboxes']), b['gt_labels'], list(b['gt_keypointss']))
+    sum(losses.values()).backward()
+    lv, grads, aux = O.train_step(b, sd, arch)
+    for k in ('loss_cls', 'loss_bbox', 'loss_obj', 'loss_kps'):
+        assert abs(float(losses[k]) - lv[k]) <= 1e-6 * abs(lv[k]) + 1e-7, k
+    ref_g = dict(model.named_parameters())
+    scale = max(float(p.grad.abs().max()) for p in ref_g.values())
+    assert set(grads) == set(ref_g)
+    for k, g in grads.items():
+        assert float((ref_g[k].grad - g).abs().max()) <= 1e-5 * scale, k
+    rs = model.state_dict()
+    for k in sd:
+        if 'running' in k:
+            assert torch.equal(rs[k], sd[k]), k
+
+
+@pytest.mark.parametrize('head', TOWER_HEADS)
+def test_tower_head_builds_like_the_reference(head):
+    """Registry surface: the same config builds here with the reference's parameter count, state_dict key order and
+    shapes, and the reference's state loads strict."""
+    import os
+    import yunet_amd
+    ref_model, _ = ref_stub.build_detector('yunet_n.py', head=head)
+    cfg = yunet_amd.Config.fromfile(os.path.join(ref_stub.REF_ROOT, 'configs', 'yunet_n.py'))
+    for k, v in head.items():
+        if v is None:
+            cfg.model.bbox_head.pop(k, None)
+        else:
+            cfg.model.bbox_head[k] = v
+    m = yunet_amd.build_detector(cfg.model)
+    assert list(m.state_dict().keys()) == list(ref_model.state_dict().keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in ref_model.state_dict().values()]
+    res = m.load_state_dict(ref_model.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert type(m.bbox_head.loss_bbox).__name__ == type(ref_model.bbox_head.loss_bbox).__name__
