@@ -287,19 +287,26 @@ int yunet_loss_finalize_ex(const float* partials, int blocks, float* losses, flo
                            const float* num_total, float* dy_norm, void* stream);
 int yunet_loss_blocks(int N, int P);
 
-/* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */
-/* g = grad*grad_scale + wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf.
- * lr is read from device memory (lr_dev[0]) so schedules do not need a re-capture. */
 /* out[i] = a[i] + b[i] (ABI 9).  The one place the reference's head concatenates predictions that come from DIFFERENT
  * inputs: with per-level towers (YuNet_Head(stacked_convs > 0), yunet_head.py:115-147, 191-207) the cls map is computed
  * from the cls tower and bbox / obj / kps from the reg tower, then flattened side by side (:456-472).  Here each tower
  * feeds one fused 64 -> 16 head unit whose rows for the other tower's channels are zero, and the two [N,P,16] outputs
- * (exact zeros in the foreign channels) are added.  n elements, 16-byte aligned pointers when n % 4 == 0. */
+ * (exact zeros in the foreign channels) are added.  `out` may alias `a`. */
 int yunet_add(const float* a, const float* b, float* out, size_t n, void* stream);
 
+/* ---- optimizer (torch.optim.SGD semantics, configs/yunet_n.py:1) --------------------- */
+/* g = grad*grad_scale + wd*p;  buf = first ? g : momentum*buf + g;  p -= lr*buf.
+ * lr is read from device memory (lr_dev[0]) so schedules do not need a re-capture. */
 int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
                    const float* lr_dev, float momentum, float weight_decay, float grad_scale,
                    int first_step, void* stream);
+/* ABI 9: the remaining arguments of torch.optim.SGD (torch/optim/sgd.py _single_tensor_sgd):
+ *   buf = first ? g : momentum*buf + (1 - dampening)*g;   p -= lr * (nesterov ? g + momentum*buf : buf);
+ * momentum == 0: p -= lr*g and momentum_buf is not touched (may be NULL).  nesterov needs momentum > 0 and
+ * dampening == 0 (YUNET_EINVAL otherwise, like torch's ValueError). */
+int yunet_sgd_step_ex(float* params, const float* grads, float* momentum_buf, int64_t n,
+                      const float* lr_dev, float momentum, float dampening, int nesterov,
+                      float weight_decay, float grad_scale, int first_step, void* stream);
 
 /* ---- op-list executor ---------------------------------------------------------------- */
 /* A training step is a fixed sequence of the calls above; the host builds it once as an
@@ -432,6 +439,7 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *   "fwd16s"             1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernels | 0: the tile kernels
  *   "stem_mma"           1 (default): the fp32 stem (yunet_stem_fwd; YUNET_OP_STEM_BWD with the stem's parameters in p[4],
  *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
+ *   "bwd32_split"        1 (default): the 32 -> 64 backward unit (YuNet_s) on the split-bf16 matrix path | 0: exact-fp32 MFMA
  *   "upadd_coarse"       1 (default): yunet_upadd_bwd with dxa = NULL on the dedicated coarse-gradient kernel | 0: general kernel
  *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 600 000; env YUNET_ONESHOT_TIMEOUT_MS)
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.

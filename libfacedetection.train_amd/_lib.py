@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('YUNET_HIP_LIB') or os.path.join(_HERE, 'libyunet_hip.
 c_f32p = C.c_void_p
 MAX_LEVELS = 5
 
+EINVAL, EOPCODE = -1, -2            # YUNET_EINVAL / YUNET_EOPCODE (include/yunet_hip.h)
 T_IDENTITY, T_BNRELU = 0, 1
 F32, BF16 = 0, 1
 BOX_EIOU, BOX_DIOU, BOX_IOU_LINEAR, BOX_IOU_SQUARE, BOX_IOU_LOG, BOX_GIOU, BOX_CIOU = 0, 1, 2, 3, 4, 5, 6
@@ -128,6 +129,8 @@ _SIGNATURES = {
                    [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'yunet_loss_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'yunet_loss_finalize_ex': (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
+    'yunet_sgd_step_ex': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_float,
+                                    C.c_float, C.c_int, C.c_void_p]),
     'yunet_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'yunet_sgd_step': (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_float, C.c_int, C.c_void_p]),

@@ -5,21 +5,24 @@
 
 namespace {
 
-// torch.optim.SGD (momentum, weight_decay, dampening 0, no nesterov) over one flat buffer
+// torch.optim.SGD (momentum, dampening, nesterov, weight_decay) over one flat buffer
 // (configs/yunet_n.py:1; weight decay hits every parameter, BN gamma/beta included).
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, long long n,
-                                                  const float* __restrict__ lr_dev, float momentum,
-                                                  float wd, float gscale, int first) {
+                                                  const float* __restrict__ lr_dev, float momentum, float undamped,
+                                                  int nesterov, float wd, float gscale, int first) {
     const float lr = lr_dev[0];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
-         i += (long long)gridDim.x * 256) {
-        const float w = p[i];
-        const float d = g[i] * gscale + wd * w;
-        const float b = first ? d : buf[i] * momentum + d;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // one element per thread: no loop (test_isa_guard)
+    if (i >= n) return;
+    const float w = p[i];
+    const float d = g[i] * gscale + wd * w;
+    float step = d;
+    if (momentum != 0.0f) {
+        const float b = first ? d : buf[i] * momentum + undamped * d;
         buf[i] = b;
-        p[i] = w - lr * b;
+        step = nesterov ? d + momentum * b : b;
     }
+    p[i] = w - lr * step;
 }
 
 // every BatchNorm layer of the model in one launch (one workgroup per layer)
@@ -95,16 +98,25 @@ extern "C" int yunet_add(const float* a, const float* b, float* out, size_t n, v
     return hip_status();
 }
 
+extern "C" int yunet_sgd_step_ex(float* params, const float* grads, float* momentum_buf, int64_t n,
+                                 const float* lr_dev, float momentum, float dampening, int nesterov,
+                                 float weight_decay, float grad_scale, int first_step, void* stream) {
+    if (n < 1 || !params || !grads || !lr_dev) return YUNET_EINVAL;
+    if (momentum != 0.0f && !momentum_buf) return YUNET_EINVAL;
+    if (nesterov && (momentum <= 0.0f || dampening != 0.0f)) return YUNET_EINVAL;      // torch: ValueError
+    const long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffll) return YUNET_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf, (long long)n, lr_dev, momentum, 1.0f - dampening, nesterov ? 1 : 0, weight_decay,
+                       grad_scale, first_step);
+    return hip_status();
+}
+
 extern "C" int yunet_sgd_step(float* params, const float* grads, float* momentum_buf, int64_t n,
                               const float* lr_dev, float momentum, float weight_decay,
                               float grad_scale, int first_step, void* stream) {
-    if (n < 1) return YUNET_EINVAL;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       momentum_buf, (long long)n, lr_dev, momentum, weight_decay, grad_scale,
-                       first_step);
-    return hip_status();
+    return yunet_sgd_step_ex(params, grads, momentum_buf, n, lr_dev, momentum, 0.0f, 0, weight_decay, grad_scale,
+                             first_step, stream);
 }
 
 // ---- measurement switches (common.h: YunetOptions) --------------------------------------------------------------
@@ -127,6 +139,7 @@ YunetOptions& yunet_options() {
         v.stem_mma = env("YUNET_STEM_MMA", 1);
         v.fwd16s = env("YUNET_FWD16S", 1);
         v.upadd_coarse = env("YUNET_UPADD_COARSE", 1);
+        v.bwd32_split = env("YUNET_BWD32_SPLIT", 1);
         v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 600000);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
@@ -150,6 +163,7 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "stem_mma")) slot = &o.stem_mma;
     else if (!strcmp(name, "fwd16s")) slot = &o.fwd16s;
     else if (!strcmp(name, "upadd_coarse")) slot = &o.upadd_coarse;
+    else if (!strcmp(name, "bwd32_split")) slot = &o.bwd32_split;
     else if (!strcmp(name, "oneshot_timeout_ms")) slot = &o.oneshot_timeout_ms;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;

@@ -236,6 +236,7 @@ struct YunetOptions {
     int fwd16s;              // 1 (default): the fp32 16 -> 16 / 16 -> 64 forward units on the wave-streaming kernel (conv_fwd16.hip)
     int stem_mma;            // 1 (default): the fp32 stem forward / weight gradient on the matrix cores (conv_stem.hip; the
                              // backward recomputes z from the image); 0: the VALU tile kernels
+    int bwd32_split;         // 1 (default): the 32 -> 64 backward unit (YuNet_s) on the split-bf16 matrix path of the 64 -> 64 units
     int upadd_coarse;        // 1 (default): yunet_upadd_bwd without a fine-tensor share (dxa = NULL) on the dedicated kernel
     int oneshot_timeout_ms;  // how long yunet_allreduce waits for a peer before it poisons the buffer and sets the status
                              // word (default 600 000 = 10 min, the process group's order of magnitude; tests use 1 000)

@@ -318,9 +318,12 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
     if constexpr (GEMM == 1) {
         // W1 -> bf16 hi / lo planes in both orientations, 8 weights per thread and pass, every global
         // load of a pass in flight at once, 16-byte LDS stores
-        static_assert(COUT * CIN == 8 * BWD_THREADS, "one 8-weight group per thread");
+        // (32 -> 64: 256 groups for 512 threads -- the upper half repeats the lower half's groups, same values to the same
+        // addresses, instead of a divergent branch)
+        static_assert(COUT * CIN <= 8 * BWD_THREADS && (8 * BWD_THREADS) % (COUT * CIN) == 0, "8-weight groups per thread");
+        const int t8 = tid % (COUT * CIN / 8);
         {
-            const int co = tid / (CIN / 8), c0 = (tid % (CIN / 8)) * 8;
+            const int co = t8 / (CIN / 8), c0 = (t8 % (CIN / 8)) * 8;
             const float4 a = *reinterpret_cast<const float4*>(d.w_pw + co * CIN + c0);
             const float4 b = *reinterpret_cast<const float4*>(d.w_pw + co * CIN + c0 + 4);
             const float w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             if (c0 == 0) s_b1[co] = d.b_pw[co];
         }
         {
-            const int ci = tid / (COUT / 8), o0 = (tid % (COUT / 8)) * 8;
+            const int ci = t8 / (COUT / 8), o0 = (t8 % (COUT / 8)) * 8;
             float w8[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) w8[j] = d.w_pw[(o0 + j) * CIN + ci];
@@ -2467,6 +2470,12 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
         const bool full816 = d->H % 8 == 0 && d->W % 16 == 0, full1632 = d->H % 16 == 0 && d->W % 32 == 0;
         if (d->cin == 16) return full1632 ? launch_dp_bwd<16, 16, 16, 32, false, 0, true, true>(d, s)
                                           : launch_dp_bwd<16, 16, 16, 32, false, 0, true>(d, s);
+        // 32 -> 64 (YuNet_s, in front of its 80 x 80 -> 40 x 40 pool): on the exact-fp32 matrix instruction this unit is
+        // MATRIX-bound (12.3 kFLOP per pixel at 157 TFLOP/s: 0.87 ms per 512-image launch = 0.16 of the HBM peak, the
+        // slowest kernel of the YuNet_s step); round 5 puts it on the split-bf16 path of the 64 -> 64 units (GEMM = 1)
+        if (d->cin == 32 && yunet_options().bwd_fp32mma == 0 && yunet_options().bwd32_split)
+            return full816 ? launch_dp_bwd<32, 64, 8, 16, false, 1, true, true>(d, s)
+                           : launch_dp_bwd<32, 64, 8, 16, false, 1, true>(d, s);
         if (d->cin == 32) return full816 ? launch_dp_bwd<32, 64, 8, 16, false, 0, true, true>(d, s)
                                          : launch_dp_bwd<32, 64, 8, 16, false, 0, true>(d, s);
         // (option bwd_fp32mma: the exact-fp32 matrix instruction for this instance too -- before round 5 the pooled-dy
@@ -2491,6 +2500,9 @@ extern "C" int ACT_SUFFIX(yunet_dp_bwd)(const YunetDP* d, void* stream) {
     }
     if (d->cin == 64 && d->cout == 64 && !f32mma)
         return bwd64_nw(d->N, d->H, d->W) == 4 ? launch_dp_bwd64<4, false, false>(d, s) : launch_dp_bwd64<8, false, false>(d, s);
+    if (d->cin == 32 && d->cout == 64 && !f32mma && yunet_options().bwd32_split)      // (plain 32 -> 64: split-bf16 as above)
+        return (d->H % 8 == 0 && d->W % 16 == 0) ? launch_dp_bwd<32, 64, 8, 16, false, 1, false, true>(d, s)
+                                                 : launch_dp_bwd<32, 64, 8, 16, false, 1>(d, s);
     if (d->H % 8 == 0 && d->W % 16 == 0) {       // whole-tile maps of the 16-channel stages (80 x 80 in the shipped nets)
         if (d->cin == 16 && d->cout == 64) return launch_dp_bwd<16, 64, 8, 16, false, 0, false, true>(d, s);
         if (d->cin == 16 && d->cout == 32) return launch_dp_bwd<16, 32, 8, 16, false, 0, false, true>(d, s);

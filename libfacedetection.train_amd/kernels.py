@@ -393,7 +393,9 @@ def loss(flat, gt_inds, ovl, gt_boxes, gt_kps, img_stats, sizes, strides, cfg, i
     return losses[:4], dflat, norm
 
 
-def sgd_step(params, grads, buf, lr_dev, momentum, weight_decay, grad_scale=1.0, first=False):
-    L.check(L.load().yunet_sgd_step(_p(params), _p(grads), _p(buf), params.numel(), _p(lr_dev),
-                                    float(momentum), float(weight_decay), float(grad_scale),
-                                    int(first), _stream()), 'yunet_sgd_step')
+def sgd_step(params, grads, buf, lr_dev, momentum, weight_decay, grad_scale=1.0, first=False, dampening=0.0,
+             nesterov=False):
+    """torch.optim.SGD's update over one flat buffer (yunet_sgd_step_ex)."""
+    L.check(L.load().yunet_sgd_step_ex(_p(params), _p(grads), _p(buf), params.numel(), _p(lr_dev),
+                                       float(momentum), float(dampening), int(bool(nesterov)), float(weight_decay),
+                                       float(grad_scale), int(first), _stream()), 'yunet_sgd_step_ex')

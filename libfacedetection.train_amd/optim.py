@@ -11,10 +11,10 @@ from . import kernels as K
 
 class FusedSGD:
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=0.0, dampening=0, nesterov=False):
-        if dampening != 0 or nesterov:
-            raise NotImplementedError('dampening / nesterov are not used by the reference configs')
+        if nesterov and (momentum <= 0 or dampening != 0):        # torch/optim/sgd.py
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
         self.model = model
-        self.defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=dampening, nesterov=nesterov)
         self.param_groups = [dict(self.defaults, initial_lr=lr, params=list(model.parameters()))]
         self._buf = None
         self._lr_dev = None
@@ -72,7 +72,8 @@ class FusedSGD:
             self._lr_dev.fill_(float(g['lr']))
             self._lr_val = g['lr']
         K.sgd_step(eng.params.data, eng.params.grad, self._buf, self._lr_dev, g['momentum'],
-                   g['weight_decay'], float(self.grad_scale), first=(self._steps == 0))
+                   g['weight_decay'], float(self.grad_scale), first=(self._steps == 0),
+                   dampening=g.get('dampening', 0.0), nesterov=g.get('nesterov', False))
         self._steps += 1
 
     def state_dict(self):

@@ -20,9 +20,8 @@ CSRC = os.path.join(ROOT, 'libfacedetection.train_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 # loops that are known and harmless: at most one or two trips (G <= Gmax ground-truth boxes per image over 256 threads,
-# 27 x 16 stem weights over 256 threads in the bf16-storage stem, the grid-stride loop of the SGD kernel)
+# 27 x 16 stem weights over 256 threads in the bf16-storage stem)
 KNOWN = {
-    ('api.hip', 'sgd_kernel'): 1,
     ('conv_fwd.hip', 'stem_fwd_kernel'): 1,
     ('loss_step.hip', 'assign_compact_kernel'): 1,
     ('loss_step.hip', 'assign_resolve_kernel'): 2,

@@ -566,23 +566,29 @@ def test_bn_running_and_param_grad():
     assert rel_err(db, x.sum(0)) < 1e-6 and rel_err(dg, (x * x).sum(0)) < 1e-6
 
 
-def test_sgd_matches_torch():
+@pytest.mark.parametrize('momentum,dampening,nesterov', [(0.9, 0.0, False), (0.9, 0.0, True), (0.9, 0.3, False), (0.0, 0.0, False)])
+def test_sgd_matches_torch(momentum, dampening, nesterov):
+    """yunet_sgd_step_ex against torch.optim.SGD itself: the shipped hyper-parameters (configs/yunet_n.py:1) and the
+    constructor's other arguments (Nesterov, dampening, no momentum)."""
     k = K()
     g = torch.Generator().manual_seed(9)
     n = 75856
     p0 = torch.randn(n, generator=g)
     ref = p0.clone().requires_grad_(True)
-    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=momentum, weight_decay=5e-4, dampening=dampening, nesterov=nesterov)
     p = p0.clone().to(DEV)
     buf = torch.zeros(n, device=DEV)
     lr = torch.tensor([0.01], device=DEV)
-    for it in range(3):
+    for it in range(4):
         gr = torch.randn(n, generator=g)
         ref.grad = gr.clone()
         opt.step()
-        k.sgd_step(p, gr.to(DEV), buf, lr, 0.9, 5e-4, first=(it == 0))
+        k.sgd_step(p, gr.to(DEV), buf, lr, momentum, 5e-4, first=(it == 0), dampening=dampening, nesterov=nesterov)
     torch.cuda.synchronize()
     assert rel_err(p, ref.detach()) < 1e-6
+    import yunet_amd._lib as L
+    rc = L.load().yunet_sgd_step_ex(p.data_ptr(), p.data_ptr(), buf.data_ptr(), n, lr.data_ptr(), 0.0, 0.0, 1, 0.0, 1.0, 0, None)
+    assert rc == L.EINVAL       # Nesterov without momentum: torch raises ValueError
 
 
 def test_reduce_partials_batch():
