@@ -182,7 +182,7 @@ def executed_bf16(name, alg_tflops, dtype):
     bf16 peak (= what MfmaUtil measures): the fp32 forward of 32 / 64-channel inputs runs 6 bf16 products per
     algorithmic product (exact 3-way split), dp_bwd64 runs 3 GEMMs (p recomputed, dW1, da) x 3 products for its
     2 algorithmic GEMMs; None for kernels on the exact fp32 instruction."""
-    if name.startswith('dp_bwd64_kernel') or (name.startswith('dp_bwd_kernel<64,64') and ',1,' in name):
+    if name.startswith('dp_bwd64_kernel') or (name.startswith('dp_bwd_kernel<') and name.split(',')[5:6] == ['1']):      # template argument GEMM = 1
         mult, what = 1.5 * 3, '3 GEMMs (p recomputed, dW1, da) x 3 bf16 MFMA products each'
     elif dtype == 'f32' and (name.startswith('dp_fwd_kernel<64,') or name.startswith('dp_fwd_kernel<32,')
                              or name.startswith('dp_fwd64s_kernel')):
@@ -309,7 +309,9 @@ def op_name(op, L):
             if (big and d.out_has_bn and d.dx and not d.accumulate_dx
                     and int(os.environ.get('YUNET_BWD16S', '1'))):
                 return f"dp_bwd16s_kernel<{'true' if d.pool_idx else 'false'}>"
-            gemm = ',0'
+            # round 5: the 32 -> 64 unit (YuNet_s) runs the split-bf16 variant (template argument 1) unless YUNET_BWD32_SPLIT=0
+            gemm = ',1' if ((d.cin, d.cout) == (32, 64) and not OPTS.get('bwd_fp32mma')
+                            and int(os.environ.get('YUNET_BWD32_SPLIT', '1'))) else ',0'
             gemm += ',true' if d.pool_idx else ',false'
             # last argument: the whole-tile instance (map = exact multiple of the tile, no validity tests)
             th, tw = (16, 32) if big else (8, 16)
