@@ -5,6 +5,7 @@ CheckpointHook + TextLoggerHook are un-vendored).
 Per iteration, exactly the reference's order: lr hook -> model.train_step(batch, optimizer)
 -> optimizer.zero_grad() -> loss.backward() -> optimizer.step() -> log buffer.
 """
+import math
 import os
 import time
 import warnings
@@ -16,22 +17,75 @@ from .optim import build_optimizer
 from .parallel import build_ddp, get_dist_info
 
 
-class StepLrWarmup:
-    """lr_config = dict(policy='step', warmup='linear', warmup_iters, warmup_ratio, step=[..])
-    with by_epoch steps (configs/yunet_n.py:4-10)."""
+class LrSchedule:
+    """lr_config = dict(policy=..., warmup=..., warmup_iters, warmup_ratio, ...) of mmcv's LrUpdaterHook family
+    (mmcv/runner/hooks/lr_updater.py, un-vendored: restated from its published formulas, SURVEY App. C -- the shipped
+    configs use policy='step' with by-epoch steps and a linear by-iteration warm-up, configs/yunet_n.py:4-10, and that
+    case is the one checked against the shipped checkpoint's optimizer state).
 
-    def __init__(self, base_lr, step, gamma=0.1, warmup='linear', warmup_iters=0,
-                 warmup_ratio=0.1, policy='step', **_):
-        assert policy == 'step'
-        self.base_lr, self.step, self.gamma = base_lr, list(step), gamma
+    policy: 'step' (step int | list, gamma, min_lr) | 'fixed' | 'exp' (gamma) | 'poly' (power, min_lr) |
+            'inv' (gamma, power) | 'CosineAnnealing' (min_lr | min_lr_ratio);  by_epoch (default True) selects the
+    progress variable (epoch / iteration) of the regular schedule;  warmup: None | 'constant' | 'linear' | 'exp',
+    always by iteration (mmcv's default warmup_by_epoch=False)."""
+
+    POLICIES = ('step', 'fixed', 'exp', 'poly', 'inv', 'CosineAnnealing')
+
+    def __init__(self, base_lr, step=None, gamma=0.1, warmup=None, warmup_iters=0, warmup_ratio=0.1, policy='step',
+                 by_epoch=True, min_lr=None, min_lr_ratio=None, power=1.0, **_):
+        if policy not in self.POLICIES:
+            raise NotImplementedError(f'lr policy {policy!r}: implemented are {self.POLICIES}')
+        if warmup not in (None, 'constant', 'linear', 'exp'):
+            raise ValueError(f'"{warmup}" is not a supported type for warming up, valid types are "constant" and "linear"')
+        if policy == 'step' and step is None:
+            raise ValueError('lr policy "step" needs step=<int | list>')
+        if policy == 'CosineAnnealing' and (min_lr is None) == (min_lr_ratio is None):
+            raise ValueError('CosineAnnealing: exactly one of min_lr / min_lr_ratio')
+        self.base_lr, self.policy, self.by_epoch = base_lr, policy, by_epoch
+        self.step = step if isinstance(step, int) or step is None else list(step)
+        self.gamma, self.power, self.min_lr, self.min_lr_ratio = gamma, power, min_lr, min_lr_ratio
         self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
 
-    def lr_at(self, epoch, it):
-        lr = self.base_lr * self.gamma ** sum(1 for s in self.step if epoch >= s)
-        if self.warmup == 'linear' and it < self.warmup_iters:
-            k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
-            lr = lr * (1 - k)
+    def regular_lr(self, epoch, it, max_epochs=None, max_iters=None):
+        progress = epoch if self.by_epoch else it
+        max_progress = max_epochs if self.by_epoch else max_iters
+        b = self.base_lr
+        if self.policy == 'fixed':
+            return b
+        if self.policy == 'step':
+            k = progress // self.step if isinstance(self.step, int) else sum(1 for s in self.step if progress >= s)
+            lr = b * self.gamma ** k
+            return max(lr, self.min_lr) if self.min_lr is not None else lr
+        if self.policy == 'exp':
+            return b * self.gamma ** progress
+        if self.policy == 'inv':
+            return b * (1 + self.gamma * progress) ** (-self.power)
+        if max_progress is None:
+            raise ValueError(f'lr policy {self.policy!r} needs the run length (max_epochs / max_iters)')
+        if self.policy == 'poly':
+            m = self.min_lr or 0.0
+            return (b - m) * (1 - progress / max_progress) ** self.power + m
+        target = b * self.min_lr_ratio if self.min_lr_ratio is not None else self.min_lr
+        return target + 0.5 * (b - target) * (math.cos(math.pi * progress / max_progress) + 1)
+
+    def lr_at(self, epoch, it, max_epochs=None, max_iters=None):
+        lr = self.regular_lr(epoch, it, max_epochs, max_iters)
+        if self.warmup is not None and it < self.warmup_iters:
+            if self.warmup == 'constant':
+                lr = lr * self.warmup_ratio
+            elif self.warmup == 'linear':
+                k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+                lr = lr * (1 - k)
+            else:
+                lr = lr * self.warmup_ratio ** (1 - it / self.warmup_iters)
         return lr
+
+
+class StepLrWarmup(LrSchedule):
+    """The shipped schedule (policy='step', linear warm-up); kept as a name for tools/make_trained_fixture.py."""
+
+    def __init__(self, base_lr, step, gamma=0.1, warmup='linear', warmup_iters=0, warmup_ratio=0.1, policy='step', **kw):
+        super().__init__(base_lr, step=step, gamma=gamma, warmup=warmup, warmup_iters=warmup_iters,
+                         warmup_ratio=warmup_ratio, policy=policy, **kw)
 
 
 class SyntheticWiderFace:
@@ -147,7 +201,8 @@ class Hook:
 
 class StepLrUpdaterHook(Hook):
     """lr_config = dict(policy='step', ...) (configs/yunet_n.py:4-10): sets the lr of every param group
-    before each iteration (by-epoch steps, by-iteration linear warm-up)."""
+    before each iteration (by-epoch steps, by-iteration linear warm-up).  The same hook carries the other policies of
+    LrSchedule (mmcv names them {Fixed,Exp,Poly,Inv,CosineAnnealing}LrUpdaterHook)."""
 
     def __init__(self, base_lr=None, **cfg):
         self.cfg, self.base_lr, self.sched = cfg, base_lr, None
@@ -155,10 +210,10 @@ class StepLrUpdaterHook(Hook):
     def before_run(self, runner):
         base = self.base_lr if self.base_lr is not None else runner.optimizer.param_groups[0].get(
             'initial_lr', runner.optimizer.param_groups[0]['lr'])
-        self.sched = StepLrWarmup(base, **self.cfg)
+        self.sched = LrSchedule(base, **self.cfg)
 
     def before_train_iter(self, runner):
-        lr = self.sched.lr_at(runner.epoch, runner.iter)
+        lr = self.sched.lr_at(runner.epoch, runner.iter, getattr(runner, 'max_epochs', None), getattr(runner, 'max_iters', None))
         for g in runner.optimizer.param_groups:
             g['lr'] = lr
 
@@ -413,6 +468,14 @@ class EpochBasedRunner:
     def max_epochs(self):
         return self._max_epochs
 
+    @property
+    def max_iters(self):
+        """mmcv EpochBasedRunner: max_epochs * len(data_loader) once the data source is known."""
+        if self._max_iters is not None:
+            return self._max_iters
+        per = getattr(self.data_source, 'iters_per_epoch', None)
+        return self._max_epochs * per if (self._max_epochs is not None and per) else None
+
     def current_lr(self):
         return [g['lr'] for g in self.optimizer.param_groups]
 
@@ -428,8 +491,8 @@ class EpochBasedRunner:
         if lr_config is not None:
             cfg = dict(lr_config)
             policy = cfg.pop('policy', 'step')
-            if policy != 'step':
-                raise NotImplementedError(f'lr policy {policy!r}: the reference configs use "step"')
+            if policy not in LrSchedule.POLICIES:
+                raise NotImplementedError(f'lr policy {policy!r}: implemented are {LrSchedule.POLICIES}')
             self.register_hook(StepLrUpdaterHook(policy=policy, **cfg), 'VERY_HIGH')
         if isinstance(optimizer_config, Hook):
             self.register_hook(optimizer_config, 'ABOVE_NORMAL')
@@ -486,6 +549,7 @@ class EpochBasedRunner:
     def run(self, data_sources, workflow=(('train', 1),), device='cuda'):
         self.device = device
         src = data_sources[0] if isinstance(data_sources, (list, tuple)) else data_sources
+        self.data_source = src
         self.call_hook('before_run')
         while self.epoch < self._max_epochs:
             if not self.train(src):

@@ -149,3 +149,42 @@ def test_fp16_hook_loss_scale_bookkeeping():
     run.outputs = dict(loss=(m.w * torch.tensor([float('inf'), 1.0])).sum())
     hd.after_train_iter(run)
     assert hd.scale == 2. ** 15 and torch.equal(m.w.detach(), before)
+
+
+def test_lr_policies_closed_forms():
+    """The policies of mmcv's LrUpdaterHook family besides the shipped 'step' (mmcv/runner/hooks/lr_updater.py,
+    un-vendored: restated formulas, hand-evaluated here)."""
+    import math
+    L = R.LrSchedule
+    assert L(0.1, policy='fixed').lr_at(7, 123) == 0.1
+    assert L(0.1, policy='step', step=3, gamma=0.5).lr_at(7, 0) == pytest.approx(0.1 * 0.5 ** 2)
+    assert L(0.1, policy='step', step=[2, 5], gamma=0.1, min_lr=0.005).lr_at(6, 0) == pytest.approx(0.005)
+    assert L(0.1, policy='step', step=[100], by_epoch=False).lr_at(0, 150) == pytest.approx(0.01)
+    assert L(0.1, policy='exp', gamma=0.9).lr_at(3, 0) == pytest.approx(0.1 * 0.9 ** 3)
+    assert L(0.1, policy='inv', gamma=0.5, power=2.0).lr_at(2, 0) == pytest.approx(0.1 * (1 + 1.0) ** -2)
+    assert L(0.1, policy='poly', power=2.0, min_lr=0.01).lr_at(5, 0, max_epochs=10) == pytest.approx((0.1 - 0.01) * 0.25 + 0.01)
+    cos = L(0.1, policy='CosineAnnealing', min_lr_ratio=0.1)
+    assert cos.lr_at(0, 0, max_epochs=10) == pytest.approx(0.1) and cos.lr_at(10, 0, max_epochs=10) == pytest.approx(0.01)
+    assert cos.lr_at(5, 0, max_epochs=10) == pytest.approx(0.01 + 0.5 * 0.09 * (math.cos(math.pi / 2) + 1))
+    # warm-up types (by iteration, on top of the regular lr)
+    assert L(0.1, policy='fixed', warmup='constant', warmup_iters=10, warmup_ratio=0.2).lr_at(0, 3) == pytest.approx(0.02)
+    assert L(0.1, policy='fixed', warmup='linear', warmup_iters=10, warmup_ratio=0.2).lr_at(0, 5) == pytest.approx(0.1 * (1 - 0.5 * 0.8))
+    assert L(0.1, policy='fixed', warmup='exp', warmup_iters=10, warmup_ratio=0.01).lr_at(0, 5) == pytest.approx(0.1 * 0.01 ** 0.5)
+    assert L(0.1, policy='fixed', warmup='linear', warmup_iters=10, warmup_ratio=0.2).lr_at(0, 10) == 0.1
+    with pytest.raises(NotImplementedError):
+        L(0.1, policy='cyclic')
+    with pytest.raises(ValueError):
+        L(0.1, policy='CosineAnnealing')
+    with pytest.raises(ValueError):
+        L(0.1, policy='poly').lr_at(1, 0)
+
+
+def test_runner_runs_a_cosine_schedule(tmp_path):
+    lines = []
+    r, m, opt = _runner(tmp_path, lines, lr_config=dict(policy='CosineAnnealing', min_lr_ratio=0.0, by_epoch=False))
+    r.run([ToySource()])
+    lrs = [lr for tag, lr in m.calls if tag == 'train_step']
+    import math
+    assert len(lrs) == 12 and r.max_iters == 12
+    for it, lr in enumerate(lrs):
+        assert lr == pytest.approx(0.5 * 0.01 * (math.cos(math.pi * it / 12) + 1))
