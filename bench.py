@@ -249,7 +249,7 @@ def live_traffic(instances, a):
         tmp = tempfile.mkdtemp(prefix='yunet_pmc_')
         try:
             subprocess.run([exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '-o', 'p',
-                            '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1',
+                            '--', sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--exact-steps',
                             '--no-cpu-baseline', '--no-roofline', '--no-exact-bwd', '--no-other-configs', '--kind', a.kind, '--size', str(a.size),
                             '--batch', str(a.batch), '--weights', a.weights, '--dtype', a.dtype],
                            capture_output=True, timeout=90, cwd=tmp, env=dict(os.environ, TMPDIR=tmp))

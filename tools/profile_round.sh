@@ -4,14 +4,15 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py      -> gpurun_out/rNN_kernel_stats.csv, rNN_trace_gaps.json
 #   3. PMC passes (FETCH_SIZE / WRITE_SIZE, separately)  -> gpurun_out/rNN_pmc_{fetch,write}.csv
 #      over tools/kbench.py on the dominant kernels + a calibration copy of known size
-R=${1:-r04}
+R=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --steps 30 --warmup 10 2>/dev/null | tail -1 > $OUT/${R}_bench.json
+# (the driver's own line: --steps 20 --warmup 5; bench.py extends the timed window to >= 0.5 s itself)
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$R -o $R -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-exact-bwd --no-other-configs > /tmp/prof_$R.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --exact-steps --no-cpu-baseline --no-roofline --no-exact-bwd --no-other-configs > /tmp/prof_$R.log 2>&1
 # keep the kernels of the step: the at::native rows (thousands of calls) are synthetic.render_faces painting the
 # input batches with torch ops BEFORE the warm-up, the __amd_rocclr_copyBuffer rows its small host-to-device
 # copies (VERDICT r2 hygiene #10)
@@ -31,7 +32,7 @@ done
 #      3b. over tools/kbench.py --calib (a 256 MiB device copy of known size: counter calibration)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${R}_$c -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact-bwd --no-other-configs > /tmp/pmc_$c.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --exact-steps --no-cpu-baseline --no-roofline --no-exact-bwd --no-other-configs > /tmp/pmc_$c.log 2>&1
   for f in $(find /tmp/pmc_${R}_$c -name "*counter_collection.csv"); do cp $f $OUT/${R}_pmc_$c.csv; done
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcc_${R}_$c -o p -- \
       python $GRAFT_REPO_ROOT/tools/kbench.py --only dp64 --reps 2 --calib > /tmp/pmcc_$c.log 2>&1
