@@ -44,9 +44,14 @@ def test_slurm_train_sh(tmp_path):
     env = _fake_python(tmp_path)
     r = subprocess.run([os.path.join(ROOT, 'tools', 'slurm_train.sh'), 'part', 'job', 'configs/yunet_n.py', 'wd',
                         '--seed', '3'], env=dict(env, GPUS='16'), capture_output=True, text=True, check=True)
-    for part in ('-p part', '--job-name=job', '--gres=gpu:8', '--ntasks=16', '--ntasks-per-node=8', '--cpus-per-task=5',
-                 'tools/train.py configs/yunet_n.py --work-dir=wd --launcher=slurm --seed 3'):
+    for part in ('--partition=part', '--job-name=job', '--gres=gpu:8', '--ntasks=16', '--ntasks-per-node=8', '--cpus-per-task=5',
+                 '--kill-on-bad-exit=1', 'tools/train.py configs/yunet_n.py --work-dir=wd --launcher=slurm --seed 3', 'IPC=0'):
         assert part in r.stdout, (part, r.stdout)
+    # fewer GPUs than a node holds: one node, that many tasks
+    r = subprocess.run([os.path.join(ROOT, 'tools', 'slurm_train.sh'), 'p', 'j', 'c.py', 'w'], env=dict(env, GPUS='4'),
+                       capture_output=True, text=True, check=True)
+    assert '--ntasks=4' in r.stdout and '--ntasks-per-node=4' in r.stdout and '--gres=gpu:4' in r.stdout
+    assert subprocess.run([os.path.join(ROOT, 'tools', 'slurm_train.sh'), 'p', 'j'], env=env, capture_output=True).returncode == 2
 
 
 def test_launcher_env_mapping():

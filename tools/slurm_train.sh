@@ -1,26 +1,25 @@
 #!/usr/bin/env bash
-# The reference's tools/slurm_train.sh: PARTITION JOB_NAME CONFIG WORK_DIR [train.py arguments ...];
-# GPUS / GPUS_PER_NODE / CPUS_PER_TASK / SRUN_ARGS from the environment.  One task per GPU;
-# train.py --launcher slurm maps SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID (yunet_amd.parallel.launcher_env).
-set -x
-PARTITION=$1
-JOB_NAME=$2
-CONFIG=$3
-WORK_DIR=$4
-GPUS=${GPUS:-8}
-GPUS_PER_NODE=${GPUS_PER_NODE:-8}
-CPUS_PER_TASK=${CPUS_PER_TASK:-5}
-SRUN_ARGS=${SRUN_ARGS:-""}
-PY_ARGS=${@:5}
-HERE=$(cd "$(dirname "$0")" && pwd)
+# Slurm launch of tools/train.py, one task per GPU.  Same command line as the reference's tools/slurm_train.sh
+# (positional: partition, job name, config, work dir, then anything for train.py; GPUS, GPUS_PER_NODE, CPUS_PER_TASK
+# and SRUN_ARGS from the environment) so existing job scripts keep working.  `--launcher slurm` makes train.py derive
+# RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR from SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID / SLURM_NODELIST
+# (yunet_amd.parallel.launcher_env).
+if [ "$#" -lt 4 ]; then
+    echo "usage: [GPUS=8] [GPUS_PER_NODE=8] [CPUS_PER_TASK=5] [SRUN_ARGS=...] $0 PARTITION JOB_NAME CONFIG WORK_DIR [train.py arguments ...]" >&2
+    exit 2
+fi
+here=$(cd "$(dirname "$0")" && pwd)
+partition=$1; job=$2; config=$3; workdir=$4
+shift 4
+ngpu=${GPUS:-8}
+per_node=${GPUS_PER_NODE:-8}
+[ "$per_node" -gt "$ngpu" ] && per_node=$ngpu
+# dmabuf IPC between the ranks of a node: RCCL and the one-shot all-reduce's peer-mapped inboxes need it
 export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
-PYTHONPATH="$HERE/..":$PYTHONPATH \
-srun -p ${PARTITION} \
-    --job-name=${JOB_NAME} \
-    --gres=gpu:${GPUS_PER_NODE} \
-    --ntasks=${GPUS} \
-    --ntasks-per-node=${GPUS_PER_NODE} \
-    --cpus-per-task=${CPUS_PER_TASK} \
-    --kill-on-bad-exit=1 \
-    ${SRUN_ARGS} \
-    python -u "$HERE/train.py" ${CONFIG} --work-dir=${WORK_DIR} --launcher="slurm" ${PY_ARGS}
+export PYTHONPATH="$here/..${PYTHONPATH:+:$PYTHONPATH}"
+set -x
+# shellcheck disable=SC2086   # SRUN_ARGS is a word list by contract
+srun --partition="$partition" --job-name="$job" \
+     --ntasks="$ngpu" --ntasks-per-node="$per_node" --gres=gpu:"$per_node" \
+     --cpus-per-task="${CPUS_PER_TASK:-5}" --kill-on-bad-exit=1 ${SRUN_ARGS:-} \
+     python -u "$here/train.py" "$config" --work-dir="$workdir" --launcher=slurm "$@"
