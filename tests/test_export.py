@@ -6,6 +6,7 @@ import json
 import os
 
 import pytest
+import torch
 
 import detect_oracle as D
 
@@ -52,3 +53,35 @@ def test_number_format():
     from yunet_amd.export import _num
     assert _num(1.0, '.3g') == '1.f' and _num(0.5, '.3g') == '0.5f'
     assert _num(1.23456e-7, '.3g') == '1.23e-07f' and _num(-12.0, '.3g') == '-12.f'
+
+
+def test_cpp_export_tower_head_live_reference():
+    """YuNet_Head's own defaults (per-level cls / reg towers, yunet_head.py:52-53, 115-147): the C++ array dump walks
+    the module tree generically, so the tower units appear where the reference tool puts them -- byte-identical to the
+    unmodified CppConvertor on the same weights."""
+    import ref_stub
+    if not ref_stub.available():
+        pytest.skip('reference tree not present')
+    import make_golden_export as M
+    import yunet_amd
+    import yunet_oracle as O
+    from yunet_amd.export import to_cpp
+    tool = M.reference_tool()
+    head = dict(stacked_convs=2, shared_stacked_convs=2)
+    ref_model, _ = ref_stub.build_detector('yunet_n.py', head=head)
+    cfg = yunet_amd.Config.fromfile(os.path.join(ref_stub.REF_ROOT, 'configs', 'yunet_n.py'))
+    cfg.model.bbox_head.update(head)
+    mine = yunet_amd.build_detector(cfg.model)
+    sd = O.init_state(mine.arch(), seed=5)
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith('running_mean'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.3
+        if k.endswith('running_var'):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    mine.load_state_dict(sd, strict=True)
+    ref_model.load_state_dict(sd, strict=True)
+    mine.eval()
+    text = to_cpp(mine)
+    assert tool.CppConvertor(ref_model).data == text
+    assert text.count('multi_level_cls_convs') > 0 and text.count('multi_level_reg_convs') > 0

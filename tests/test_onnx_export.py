@@ -25,8 +25,8 @@ def _expected(sd, arch, x):
     return want
 
 
-def _state(kind, seed):
-    arch = O.yunet_arch(kind)
+def _state(kind, seed, **arch_kw):
+    arch = O.yunet_arch(kind, **arch_kw)
     sd = O.init_state(arch, seed)
     g = torch.Generator().manual_seed(seed)
     for k in sd:                                     # non-trivial running statistics / affine terms
@@ -53,6 +53,28 @@ def test_export_numerics_vs_oracle(kind, hw, dynamic, tmp_path):
         for k in want:
             assert got[k].shape == want[k].shape, k
             assert float((got[k] - want[k]).abs().max()) <= 1e-4 * max(1.0, float(want[k].abs().max())), k
+
+
+def test_export_tower_head_numerics_vs_oracle(tmp_path):
+    """YuNet_Head's own defaults (shared_stacked_convs = 2, stacked_convs = 2: per-level cls / reg towers,
+    yunet_head.py:115-147, 191-207): the exported graph takes cls from the cls tower and bbox / obj / kps from the reg
+    tower -- numerics against the oracle's eval forward (pinned to the reference for this head in
+    tests/test_oracle_vs_reference.py), and the node count grows by the 12 tower units + 3 more share units."""
+    from yunet_amd.onnx_export import export_onnx
+    arch, sd = _state('n', 5, stacked_convs=2, shared_stacked_convs=2)
+    path = str(tmp_path / 't.onnx')
+    export_onnx(sd, arch, path, input_shape=(160, 160))
+    m = OM.load(path)
+    x = torch.rand(1, 3, 160, 160, generator=torch.Generator().manual_seed(2)) * 255
+    got, want = OM.run(m, x), _expected(sd, arch, x)
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert float((got[k] - want[k]).abs().max()) <= 1e-4 * max(1.0, float(want[k].abs().max())), k
+    # a unit is Conv (1x1) + Conv (3x3 depthwise, BN folded) + Relu: 15 more units than the shipped YuNet_n graph
+    arch0, sd0 = _state('n', 5)
+    export_onnx(sd0, arch0, str(tmp_path / 'n.onnx'), input_shape=(160, 160))
+    n_nodes = lambda mm: len(mm.nodes) if hasattr(mm, 'nodes') else len(mm['nodes'])          # noqa: E731
+    assert n_nodes(m) == n_nodes(OM.load(str(tmp_path / 'n.onnx'))) + 15 * 3
 
 
 @pytest.mark.skipif(not os.path.exists(REF_ONNX), reason='reference tree not present')
