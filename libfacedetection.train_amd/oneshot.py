@@ -53,16 +53,23 @@ class OneShotAllReduce:
         except Exception as e:          # noqa: BLE001 -- reported to every rank below
             err = f'rank {self.rank}: {e!r}'
         reports = [None] * self.world
-        dist.all_gather_object(reports, (err, handle_bytes), group=group)
+        dist.all_gather_object(reports, (err, handle_bytes, self.device.index if self.device.index is not None
+                                         else torch.cuda.current_device()), group=group)
         self._agree([r[0] for r in reports])
         err = None
         try:
+            # peer access between every pair of devices involved (one node): mapping a peer's inbox without it would turn
+            # the first store into a memory fault instead of an error code
+            mine = reports[self.rank][2]
+            for r, (_, _, idx) in enumerate(reports):
+                if idx != mine and not torch.cuda.can_device_access_peer(mine, idx):
+                    raise RuntimeError(f'device {mine} cannot access its peer {idx} (rank {r}): no xGMI / PCIe peer path')
             with torch.cuda.device(self.device):
                 comm = L.YunetComm()
                 comm.rank, comm.world, comm.seq = self.rank, self.world, 0
                 comm.slot_bytes = (nbytes - 4096) // (2 * self.world)
                 comm.status = self._status
-                for r, (_, h) in enumerate(reports):
+                for r, (_, h, _) in enumerate(reports):
                     if r == self.rank:
                         comm.inbox[r] = self._inbox
                         continue
