@@ -140,6 +140,7 @@ YunetOptions& yunet_options() {
         v.fwd16s = env("YUNET_FWD16S", 1);
         v.upadd_coarse = env("YUNET_UPADD_COARSE", 1);
         v.bwd32_split = env("YUNET_BWD32_SPLIT", 1);
+        v.assign_v2 = env("YUNET_ASSIGN_V2", 1);
         v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 600000);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
@@ -147,6 +148,7 @@ YunetOptions& yunet_options() {
     }();
     return o;
 }
+int yunet_option_assign_v2() { return yunet_options().assign_v2; }
 extern "C" int yunet_set_option(const char* name, int value) {
     YunetOptions& o = yunet_options();
     int* slot = nullptr;
@@ -164,6 +166,7 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "fwd16s")) slot = &o.fwd16s;
     else if (!strcmp(name, "upadd_coarse")) slot = &o.upadd_coarse;
     else if (!strcmp(name, "bwd32_split")) slot = &o.bwd32_split;
+    else if (!strcmp(name, "assign_v2")) slot = &o.assign_v2;
     else if (!strcmp(name, "oneshot_timeout_ms")) slot = &o.oneshot_timeout_ms;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;

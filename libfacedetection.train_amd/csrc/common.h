@@ -238,10 +238,13 @@ struct YunetOptions {
                              // backward recomputes z from the image); 0: the VALU tile kernels
     int bwd32_split;         // 1 (default): the 32 -> 64 backward unit (YuNet_s) on the split-bf16 matrix path of the 64 -> 64 units
     int upadd_coarse;        // 1 (default): yunet_upadd_bwd without a fine-tensor share (dxa = NULL) on the dedicated kernel
+    int assign_v2;           // 1 (default): the SimOTA assignment on the chunk-balanced / candidate-pruned launches
+                             // (loss_step.hip, round 5); 0: one workgroup per image + full evaluation of every pair
     int oneshot_timeout_ms;  // how long yunet_allreduce waits for a peer before it poisons the buffer and sets the status
                              // word (default 600 000 = 10 min, the process group's order of magnitude; tests use 1 000)
 };
 YunetOptions& yunet_options();
+int yunet_option_assign_v2();      // (for loss_step.hip, which does not include this header)
 
 // ---- per-device launch set-up ------------------------------------------------------------------------------------
 // hipFuncSetAttribute (the raised dynamic-LDS limit) and the occupancy query are PER DEVICE, and executor lanes are per
