@@ -271,7 +271,8 @@ def live_traffic(instances, a):
 
 # the dispatcher options this process started with (include/yunet_hip.h: yunet_set_option reads the same variables once)
 OPTS = {'no_pack': bool(os.environ.get('YUNET_NO_PACK')), 'bwd_fp32mma': bool(os.environ.get('YUNET_BWD_FP32MMA')),
-        'bwd64_nw': int(os.environ.get('YUNET_BWD64_NW') or 0)}
+        'bwd64_nw': int(os.environ.get('YUNET_BWD64_NW') or 0),
+        'fwd_group': int(os.environ.get('YUNET_FWD_GROUP', '1'))}
 
 
 def op_name(op, L):
@@ -347,32 +348,43 @@ def profile_ops(eng, reps=3):
     for rep in range(reps + 1):
         for arr in (plan.c_fwd_a, plan.c_fwd_b, plan.c_bwd):
             evs = []
-            for k in range(len(arr)):
+            k = 0
+            while k < len(arr):
                 if arr[k].opcode in (L.OP_FORK, L.OP_JOIN):
+                    k += 1
                     continue
+                # a group of independent units (YunetOp.i[OP_GROUP]) is ONE launch: timed as the step runs it
+                g = int(arr[k].i[L.OP_GROUP]) if arr[k].opcode == L.OP_DP_FWD else 0
+                g = g if 2 <= g <= L.DP_GROUP_MAX and k + g <= len(arr) else 1
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = eng.lib.yunet_exec(C.cast(C.byref(arr, k * C.sizeof(L.YunetOp)),
-                                               C.POINTER(L.YunetOp)), 1, sptr)
+                                               C.POINTER(L.YunetOp)), g, sptr)
                 e1.record(stream)
                 assert rc == 0, rc
-                evs.append((k, e0, e1))
+                evs.append((k, g, e0, e1))
+                k += g
             torch.cuda.synchronize()
             if rep == 0:
                 continue            # warm-up pass
-            for k, e0, e1 in evs:
+            for k, g, e0, e1 in evs:
                 op = arr[k]
-                a = agg.setdefault(op_name(op, L), dict(launches=0, ms=0.0, bytes=0, flops=0))
+                members = [arr[k + j] for j in range(g)]
+                name = op_name(op, L)
+                if g > 1 and name == 'dp_fwd64s_kernel<false>' and OPTS.get('fwd_group', 1):
+                    name = 'dp_fwd64s_group_kernel'          # (csrc/conv_fwd64.hip: the units' grids in one launch)
+                a = agg.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0))
                 a['launches'] += 1
                 a['ms'] += e0.elapsed_time(e1)
-                a['bytes'] += op_bytes(op, L)
-                a['ref_bytes'] = a.get('ref_bytes', 0) + op_bytes_reference_graph(op, L)
-                a['flops'] += op_flops(op, L)
+                a['bytes'] += sum(op_bytes(m, L) for m in members)
+                a['ref_bytes'] = a.get('ref_bytes', 0) + sum(op_bytes_reference_graph(m, L) for m in members)
+                a['flops'] += sum(op_flops(m, L) for m in members)
                 if op.opcode in (L.OP_DP_FWD, L.OP_DP_BWD):      # the same instance runs on several map sizes
-                    sh = a.setdefault('shapes', {}).setdefault(f'{op.dp.H}x{op.dp.W}', dict(launches=0, ms=0.0, bytes=0))
+                    label = '+'.join(f'{m.dp.H}x{m.dp.W}' for m in members)
+                    sh = a.setdefault('shapes', {}).setdefault(label, dict(launches=0, ms=0.0, bytes=0))
                     sh['launches'] += 1
                     sh['ms'] += e0.elapsed_time(e1)
-                    sh['bytes'] += op_bytes(op, L)
+                    sh['bytes'] += sum(op_bytes(m, L) for m in members)
     eng.lib.yunet_exec_lanes(1)
     for a in agg.values():
         a['launches'] //= reps

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 9
+#define YUNET_ABI_VERSION 10
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -106,6 +106,14 @@ typedef struct YunetDP {
 
 /* ---- conv stack (mmdet/models/utils/yunet_layer.py, backbones/yunet_backbone.py:33-41,
  *      necks/tfpn.py:33-45, dense_heads/yunet_head.py:175-247) ------------------- */
+
+/* ABI 10: n <= YUNET_DP_GROUP_MAX mutually INDEPENDENT ConvDPUnit forwards in one launch where the kernels allow it (plain
+ * 64 -> 64 units on the wave-streaming kernel: the share convs of the pyramid levels, yunet_head.py:175-247, which the
+ * reference walks in a Python loop); otherwise the units are launched one after the other.  Every unit computes exactly
+ * what yunet_dp_fwd computes for it (same grid, same band height); only launch boundaries disappear.  Nothing may
+ * connect the units: no output of one is an input (or a BatchNorm sum block) of another. */
+#define YUNET_DP_GROUP_MAX 3
+int yunet_dp_fwd_group(const YunetDP* const* units, int n, void* stream);
 
 /* Conv_head.conv1: 3x3 stride-2 conv 3->cmid (+bias), NCHW image in, NHWC raw out,
  * BN statistics accumulated (yunet_layer.py:51-52,58). cmid must be 16. */
@@ -330,6 +338,11 @@ enum {
  * (everything on `stream`, FORK / JOIN become no-ops): per-launch timing, debugging. */
 #define YUNET_OP_LANE 10
 #define YUNET_MAX_LANES 2
+/* Groups (ABI 10).  A YUNET_OP_DP_FWD op with i[YUNET_OP_GROUP] = g in 2 .. YUNET_DP_GROUP_MAX declares that it and the
+ * g - 1 ops after it (all YUNET_OP_DP_FWD, same lane, same storage type) are mutually independent: the executor hands them
+ * to yunet_dp_fwd_group in one call.  0 / 1: an ordinary op.  An executor call that starts in the middle of a group (a
+ * one-op replay for timing) runs the ops one by one. */
+#define YUNET_OP_GROUP 9
 typedef struct YunetOp {
     int32_t opcode;
     int32_t i[12];
@@ -354,6 +367,7 @@ int yunet_stem_bwd_bf16(const float* img, const float* z, const float* dy, const
                         float* wgrad_partials, int wgrad_blocks, int N, int H, int W, int cmid,
                         void* stream);
 int yunet_dp_fwd_bf16(const YunetDP* d, void* stream);
+int yunet_dp_fwd_group_bf16(const YunetDP* const* units, int n, void* stream);
 int yunet_dp_bwd_bf16(const YunetDP* d, void* stream);
 int yunet_pool_fwd_bf16(const float* z, const YunetBN* bn, float* out, int N, int H, int W, int C,
                         void* stream);

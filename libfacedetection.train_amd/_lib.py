@@ -21,6 +21,7 @@ BOX_EIOU, BOX_DIOU, BOX_IOU_LINEAR, BOX_IOU_SQUARE, BOX_IOU_LOG, BOX_GIOU, BOX_C
  OP_UPADD_BWD, OP_BN_RUNNING, OP_BN_PARAM_GRAD, OP_REDUCE_PARTIALS, OP_ASSIGN, OP_LOSS_NORM,
  OP_LOSS, OP_LOSS_FINALIZE, OP_SGD, OP_MEMSET, OP_BN_BATCH, OP_REDUCE_BATCH, OP_FORK, OP_JOIN, OP_ADD) = range(1, 23)
 OP_LANE, MAX_LANES = 10, 2          # YunetOp.i[OP_LANE]: side stream of the op (0 = the caller's stream)
+OP_GROUP, DP_GROUP_MAX = 9, 3       # YunetOp.i[OP_GROUP] = g: this DP_FWD op and the g - 1 after it are independent (ABI 10)
 
 
 class YunetBN(C.Structure):
@@ -88,6 +89,7 @@ _SIGNATURES = {
     'yunet_stem_bwd_rz': (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     'yunet_dp_fwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
     'yunet_dp_bwd': (C.c_int, [C.POINTER(YunetDP), C.c_void_p]),
+    'yunet_dp_fwd_group': (C.c_int, [C.POINTER(C.POINTER(YunetDP)), C.c_int, C.c_void_p]),
     'yunet_dp_bwd_blocks': (C.c_int, [C.c_int] * 5),
     'yunet_stem_bwd_blocks': (C.c_int, [C.c_int] * 3),
     'yunet_pool_fwd': (C.c_int, [C.c_void_p, C.POINTER(YunetBN), C.c_void_p] + [C.c_int] * 4 +
@@ -146,7 +148,7 @@ _SIGNATURES = {
     'yunet_allreduce': (C.c_int, [C.POINTER(YunetComm), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     'yunet_comm_status': (C.c_int, [C.POINTER(YunetComm)]),
 }
-for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_pool_fwd', 'yunet_pool_bwd',
+for _n in ('yunet_stem_fwd', 'yunet_stem_bwd', 'yunet_dp_fwd', 'yunet_dp_bwd', 'yunet_dp_fwd_group', 'yunet_pool_fwd', 'yunet_pool_bwd',
            'yunet_pool_bwd_add', 'yunet_upadd_fwd', 'yunet_upadd_bwd'):
     _SIGNATURES[_n + '_bf16'] = _SIGNATURES[_n]      # same arguments, bf16 activation storage
 
@@ -174,7 +176,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 9:
+    if lib.yunet_abi_version() != 10:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -141,6 +141,7 @@ YunetOptions& yunet_options() {
         v.upadd_coarse = env("YUNET_UPADD_COARSE", 1);
         v.bwd32_split = env("YUNET_BWD32_SPLIT", 1);
         v.assign_v2 = env("YUNET_ASSIGN_V2", 1);
+        v.fwd_group = env("YUNET_FWD_GROUP", 1);
         v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 600000);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
@@ -167,6 +168,7 @@ extern "C" int yunet_set_option(const char* name, int value) {
     else if (!strcmp(name, "upadd_coarse")) slot = &o.upadd_coarse;
     else if (!strcmp(name, "bwd32_split")) slot = &o.bwd32_split;
     else if (!strcmp(name, "assign_v2")) slot = &o.assign_v2;
+    else if (!strcmp(name, "fwd_group")) slot = &o.fwd_group;
     else if (!strcmp(name, "oneshot_timeout_ms")) slot = &o.oneshot_timeout_ms;
     if (!slot || value < 0) return YUNET_EINVAL;
     if (slot == &o.bwd64_nw && value != 0 && value != 4 && value != 8) return YUNET_EINVAL;
@@ -181,6 +183,7 @@ extern "C" {
 int yunet_stem_fwd_bf16(const float*, const float*, const float*, float*, double*, int, int, int, int, void*);
 int yunet_stem_bwd_bf16(const float*, const float*, const float*, const YunetBN*, float*, int, int, int, int, int, void*);
 int yunet_dp_fwd_bf16(const YunetDP*, void*);
+int yunet_dp_fwd_group_bf16(const YunetDP* const*, int, void*);
 int yunet_dp_bwd_bf16(const YunetDP*, void*);
 int yunet_pool_fwd_bf16(const float*, const YunetBN*, float*, int, int, int, int, void*);
 int yunet_pool_bwd_bf16(const float*, const YunetBN*, const float*, float*, int, int, int, int, int, void*);
@@ -269,9 +272,26 @@ extern "C" int yunet_exec(const YunetOp* ops, int n_ops, void* main_stream) {
                                     &o.bn[0], (float*)o.p[3], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3],
                                     stream);
                 break;
-            case YUNET_OP_DP_FWD:
+            case YUNET_OP_DP_FWD: {
+                // a group of independent units (include/yunet_hip.h: YUNET_OP_GROUP): one call, and where the kernels allow
+                // it one launch
+                const int g = o.i[YUNET_OP_GROUP];
+                if (g >= 2 && g <= YUNET_DP_GROUP_MAX && k + g <= n_ops) {
+                    const YunetDP* units[YUNET_DP_GROUP_MAX];
+                    bool ok = true;
+                    for (int j = 0; j < g; ++j) {
+                        const YunetOp& oj = ops[k + j];
+                        ok = ok && oj.opcode == YUNET_OP_DP_FWD && oj.i[YUNET_OP_LANE] == lane && oj.dp.x_dtype == o.dp.x_dtype;
+                        units[j] = &oj.dp;
+                    }
+                    if (!ok) return YUNET_EINVAL * 1000 - k;
+                    rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_fwd_group_bf16(units, g, stream) : yunet_dp_fwd_group(units, g, stream);
+                    if (rc == 0) k += g - 1;
+                    break;
+                }
                 rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_fwd_bf16(&o.dp, stream) : yunet_dp_fwd(&o.dp, stream);
                 break;
+            }
             case YUNET_OP_DP_BWD:
                 rc = o.dp.x_dtype == YUNET_BF16 ? yunet_dp_bwd_bf16(&o.dp, stream) : yunet_dp_bwd(&o.dp, stream);
                 break;

@@ -238,6 +238,7 @@ struct YunetOptions {
                              // backward recomputes z from the image); 0: the VALU tile kernels
     int bwd32_split;         // 1 (default): the 32 -> 64 backward unit (YuNet_s) on the split-bf16 matrix path of the 64 -> 64 units
     int upadd_coarse;        // 1 (default): yunet_upadd_bwd without a fine-tensor share (dxa = NULL) on the dedicated kernel
+    int fwd_group;           // 1 (default): yunet_dp_fwd_group launches independent plain 64 -> 64 units as one grid; 0: one by one
     int assign_v2;           // 1 (default): the SimOTA assignment on the chunk-balanced / candidate-pruned launches
                              // (loss_step.hip, round 5); 0: one workgroup per image + full evaluation of every pair
     int oneshot_timeout_ms;  // how long yunet_allreduce waits for a peer before it poisons the buffer and sets the status
@@ -370,6 +371,7 @@ static inline int hip_status() { return -(int)hipGetLastError(); }
 
 // conv_fwd64.hip: the plain fp32 64 -> 64 forward unit (no packing, no fused pooling)
 int ACT_SUFFIX(launch_dp_fwd64s)(const YunetDP* d, hipStream_t stream);
+int ACT_SUFFIX(launch_dp_fwd64s_group)(const YunetDP* const* ds, int n, hipStream_t stream);     // independent plain units, one grid
 // conv_bwd16.hip: backward of the fp32 16 -> 16 unit (plain or pooled dy), z recomputed from x
 int ACT_SUFFIX(launch_dp_bwd16s)(const YunetDP* d, hipStream_t stream);
 // conv_fwd16.hip: forward of the fp32 16 -> 16 (plain | fused pooling) and 16 -> 64 units

@@ -798,6 +798,28 @@ extern "C" int ACT_SUFFIX(yunet_dp_fwd)(const YunetDP* d, void* stream) {
     return YUNET_EINVAL;
 }
 
+// Independent units in one call (include/yunet_hip.h).  One launch when every unit is a plain 64 -> 64 unit that
+// yunet_dp_fwd would put on the wave-streaming kernel (conv_fwd64.hip) -- the same tests as above, in the same order --
+// else the units go out one after the other.
+extern "C" int ACT_SUFFIX(yunet_dp_fwd_group)(const YunetDP* const* units, int n, void* stream) {
+    if (!units || n < 1 || n > YUNET_DP_GROUP_MAX) return YUNET_EINVAL;
+    bool one_grid = n >= 2 && yunet_options().fwd_group != 0;
+    for (int i = 0; i < n && one_grid; ++i) {
+        const YunetDP* d = units[i];
+        one_grid = d && d->x_dtype == YUNET_ACT_DTYPE && d->z_dtype == YUNET_ACT_DTYPE && d->cin == 64 && d->cout == 64 &&
+                   !d->pool_out && !d->prof && yunet_options().fwd64s != 0 &&
+                   (d->in_transform == YUNET_T_IDENTITY || d->in_transform == YUNET_T_BNRELU) &&
+                   !(dp_use_pack(d->N, d->H, d->W, d->cin, d->cout) && yunet_options().fwd64s < 2);
+    }
+    if (one_grid) return ACT_SUFFIX(launch_dp_fwd64s_group)(units, n, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i) {
+        if (!units[i]) return YUNET_EINVAL;
+        const int rc = ACT_SUFFIX(yunet_dp_fwd)(units[i], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int ACT_SUFFIX(yunet_pool_fwd)(const float* z, const YunetBN* bn, float* out, int N, int H, int W,
                                           int C, void* stream) {
     if ((H & 1) || (W & 1) || (C & 3) || (256 % (C / 4)) || C > 64) return YUNET_EINVAL;

@@ -65,8 +65,10 @@ __device__ __forceinline__ float med3(float a, float b, float c) { return __buil
 // (conv_fwd.hip: dp_fwd_kernel<..., POOL> -- the same rule: maximum for gamma > 0, minimum for gamma < 0, first element
 // for gamma == 0, ties to the smaller position).  A lane owns column PAIRS, so a window needs no cross-lane step: the
 // even row of a pair waits in registers for the odd one (16 more registers: this instance runs two waves per SIMD).
+// `first` / `nblk`: this workgroup's number inside the grid of ITS unit and the size of that grid (a launch may carry
+// the grids of several independent units one after the other: dp_fwd64s_group_kernel below)
 template <bool POOL>
-__global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(const YunetDP d, const int R) {
+__device__ __forceinline__ void dp_fwd64s_body(const YunetDP& d, const int R, const int first, const int nblk) {
     using namespace f64s;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* s_w1p = reinterpret_cast<__bf16*>(smem);
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
     const int tasks_img = strips * bands, ntasks = d.N * tasks_img;
     const unsigned xbytes = (unsigned)(H * W * C) * ACT_B;        // x and z: [H][W][64] in the activation storage type
     const int cq = l15, cgrp = g;                       // depthwise role of the lane: channel quad, column group
-    const int total_waves = (int)gridDim.x * WAVES;
+    const int total_waves = nblk * WAVES;
 
-    for (int t = first_tile() * WAVES + wid; t < ntasks; t += total_waves) {
+    for (int t = first * WAVES + wid; t < ntasks; t += total_waves) {
         const int n = t / tasks_img, rr = t - n * tasks_img;
         const int band = rr / strips, strip = rr - band * strips;
         const int y0 = band * R, y1 = (y0 + R < H) ? y0 + R : H;
@@ -408,6 +410,34 @@ __global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(con
     }
 }
 
+template <bool POOL>
+__global__ __launch_bounds__(f64s::NTHR, POOL ? 2 : 3) void dp_fwd64s_kernel(const YunetDP d, const int R) {
+    dp_fwd64s_body<POOL>(d, R, first_tile(), (int)gridDim.x);
+}
+
+// Several mutually independent plain units in ONE grid (the share convs of the three pyramid levels: yunet_head.py:175-247
+// walks the levels in a Python loop, nothing connects them).  Workgroups start[i] .. start[i + 1] - 1 belong to unit i and
+// do exactly what they would do in a launch of their own (same band height, same grid size, same order of the additions):
+// what the group saves is the launch boundaries -- on the 20 x 20 / 10 x 10 levels a launch is a prologue, one or two
+// bands per wave and a drain (27 / 13 us for 13 + 3 MB), and the chip idles in between.
+struct Fwd64sGroup {
+    YunetDP d[YUNET_DP_GROUP_MAX];
+    int R[YUNET_DP_GROUP_MAX];
+    int start[YUNET_DP_GROUP_MAX + 1];
+};
+__global__ __launch_bounds__(f64s::NTHR, 3) void dp_fwd64s_group_kernel(const Fwd64sGroup m) {
+    const int b = (int)blockIdx.x;
+    int u = 0;
+#pragma unroll
+    for (int i = 1; i < YUNET_DP_GROUP_MAX; ++i) u = b >= m.start[i] ? i : u;
+    const int base = m.start[u], nblk = m.start[u + 1] - base;
+    // the XCD-contiguous renumbering of first_tile(), inside the unit's own grid (hardware deals workgroup ids to the
+    // 8 XCDs round-robin: valid where the grid starts at a multiple of 8 and has a multiple of 8 workgroups)
+    const int l = b - base;
+    const int first = (YUNET_XCD_REMAP && (nblk & 7) == 0 && (base & 7) == 0) ? (l & 7) * (nblk >> 3) + (l >> 3) : l;
+    dp_fwd64s_body<false>(m.d[u], m.R[u], first, nblk);
+}
+
 }  // namespace
 
 // rows per band: the tallest bands (least row-halo recompute) that still give every resident wave a band
@@ -425,6 +455,19 @@ static int fwd64s_rows(int N, int H, int W, int waves) {
     return R;
 }
 
+// grid and band height of one unit (the same whether it is launched alone or inside a group)
+static int fwd64s_geometry(const YunetDP* d, int blocks_per_cu, bool pool, int* R_out) {
+    if ((long long)d->H * d->W * 64 * 4 >= (1ll << 31)) return -1;                // 32-bit byte offsets per image
+    int grid = yunet_cu_count() * blocks_per_cu;
+    int R = fwd64s_rows(d->N, d->H, d->W, grid * f64s::WAVES);
+    if (pool && (R & 1)) ++R;                                                      // bands hold whole row pairs
+    const long long tasks = (long long)d->N * ((d->W + f64s::TW - 1) / f64s::TW) * ((d->H + R - 1) / R);
+    const long long need = (tasks + f64s::WAVES - 1) / f64s::WAVES;
+    if (need < grid) grid = (int)need;
+    *R_out = R;
+    return grid;
+}
+
 template <bool POOL>
 static int launch_fwd64s(const YunetDP* d, hipStream_t stream) {
     static PerDevice per_cu;        // resident workgroups per CU, per device (common.h)
@@ -436,14 +479,41 @@ static int launch_fwd64s(const YunetDP* d, hipStream_t stream) {
         return nb > 3 ? 3 : nb;
     });
     if (blocks_per_cu < 1) return YUNET_EINVAL;
-    if ((long long)d->H * d->W * 64 * 4 >= (1ll << 31)) return YUNET_EINVAL;      // 32-bit byte offsets per image
-    int grid = yunet_cu_count() * blocks_per_cu;
-    int R = fwd64s_rows(d->N, d->H, d->W, grid * f64s::WAVES);
-    if (POOL && (R & 1)) ++R;                                                      // bands hold whole row pairs
-    const long long tasks = (long long)d->N * ((d->W + f64s::TW - 1) / f64s::TW) * ((d->H + R - 1) / R);
-    const long long need = (tasks + f64s::WAVES - 1) / f64s::WAVES;
-    if (need < grid) grid = (int)need;
+    int R = 0;
+    const int grid = fwd64s_geometry(d, blocks_per_cu, POOL, &R);
+    if (grid < 1) return YUNET_EINVAL;
     hipLaunchKernelGGL(dp_fwd64s_kernel<POOL>, dim3(grid), dim3(f64s::NTHR), f64s::SMEM, stream, *d, R);
+    return hip_status();
+}
+
+// n <= YUNET_DP_GROUP_MAX plain (no fused pooling) 64 -> 64 units of this activation type in one grid; the caller
+// (yunet_dp_fwd_group, conv_fwd.hip) has checked that every one of them would take this kernel on its own
+int ACT_SUFFIX(launch_dp_fwd64s_group)(const YunetDP* const* ds, int n, hipStream_t stream) {
+    static PerDevice per_cu;
+    const int blocks_per_cu = per_device(per_cu, [] {
+        const void* fn = reinterpret_cast<const void*>(dp_fwd64s_group_kernel);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f64s::SMEM) != hipSuccess) return -1;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, f64s::NTHR, f64s::SMEM) != hipSuccess || nb < 1) nb = 1;
+        return nb > 3 ? 3 : nb;
+    });
+    if (blocks_per_cu < 1 || n < 1 || n > YUNET_DP_GROUP_MAX) return YUNET_EINVAL;
+    Fwd64sGroup m;
+    int at = 0;
+    for (int i = 0; i < YUNET_DP_GROUP_MAX; ++i) {
+        m.start[i] = at;
+        if (i < n) {
+            m.d[i] = *ds[i];
+            const int g = fwd64s_geometry(ds[i], blocks_per_cu, false, &m.R[i]);
+            if (g < 1) return YUNET_EINVAL;
+            at += g;
+        } else {
+            m.d[i] = *ds[0];          // (no workgroup maps to it)
+            m.R[i] = m.R[0];
+        }
+    }
+    m.start[YUNET_DP_GROUP_MAX] = at;
+    hipLaunchKernelGGL(dp_fwd64s_group_kernel, dim3(at), dim3(f64s::NTHR), f64s::SMEM, stream, m);
     return hip_status();
 }
 

@@ -349,16 +349,42 @@ class Plan:
             else:
                 self._head(f, l, bases[l])
             self._lane = 0
+        # Round 5: the head chains wait until the whole top-down pathway is built, and the share convs of the levels --
+        # mutually independent plain 64 -> 64 units -- are emitted next to each other as ONE group
+        # (YunetOp.i[OP_GROUP]): the executor launches them as one grid (yunet_dp_fwd_group).  On the 20 x 20 / 10 x 10
+        # levels a launch of their own is a prologue, one or two bands per wave and a drain (27 / 13 us for 13 + 3 MB).
+        # Needs no lanes (one stream); the tower head (stacked_convs > 0) keeps the per-level order.
+        grouped = (not lanes_ok and not self.towers and not os.environ.get('YUNET_NO_HEAD_GROUP')
+                   and arch['shared_stacked_convs'] >= 1)
         for i in range(len(feats) - 1, 0, -1):
             feats[i] = self._dp(feats[i], f'neck.lateral_convs.{i}')
-            head_chain(i)
+            if not grouped:
+                head_chain(i)
             # the backward of this merge ACCUMULATES into feats[i]'s gradient after the level's head chain (on its
             # lane) has written it: the executor joins that lane first
             self._join_before = getattr(feats[i], 'head_lane', None)
             feats[i - 1] = self._upadd(feats[i - 1], feats[i])
             self._join_before = None
         feats[0] = self._dp(feats[0], 'neck.lateral_convs.0')
-        head_chain(0)
+        if not grouped:
+            head_chain(0)
+        else:
+            order = [i for i in range(len(feats)) if level_of.get(i) is not None]        # finest (largest) map first
+            cur = {}
+            for i in order:
+                assert (feats[i].h, feats[i].w) == self.sizes[level_of[i]], 'feature sizes vs strides'
+                cur[i] = feats[i]
+            for j in range(arch['shared_stacked_convs']):
+                for s0 in range(0, len(order), L.DP_GROUP_MAX):
+                    part = order[s0:s0 + L.DP_GROUP_MAX]
+                    first = len(self.fwd_a)
+                    for i in part:
+                        cur[i] = self._dp(cur[i], f'bbox_head.multi_level_share_convs.{level_of[i]}.{j}')
+                    if len(part) >= 2:
+                        assert len(self.fwd_a) == first + len(part)
+                        self.fwd_a[first].i[L.OP_GROUP] = len(part)
+            for i in order:
+                self._head(cur[i], level_of[i], bases[level_of[i]])
         if self.lanes_used:
             self.fwd_a.append(self._op(L.OP_JOIN, i=[self.lanes_used]))
         if self.towers:      # flat = (reg tower's bbox | obj | kps channels) + (cls tower's cls channel): exact zeros elsewhere

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/yunet_hip.h but not exported'
     assert sorted(L.EXPORTED) == names, 'ctypes signature table and header disagree'
-    assert lib.yunet_abi_version() == 9
+    assert lib.yunet_abi_version() == 10
     assert lib.yunet_conv_blocks() >= 256
     assert lib.yunet_loss_blocks(256, 2100) >= 1
 

@@ -25,6 +25,12 @@ KNOWN = {
     ('conv_fwd.hip', 'stem_fwd_kernel'): 1,
     ('loss_step.hip', 'assign_compact_kernel'): 1,
     ('loss_step.hip', 'assign_resolve_kernel'): 2,
+    # round 5 (assign_v2): the GT boxes of an image beyond the first 512 / 1024 (zero trips at Gmax <= 512), the chunk
+    # counts of an image (one trip: ceil(P / 256) <= 1024), the pair-list offset (one trip for up to 512 images), the
+    # prefix scan over blocks of 64 chunk counts (one trip up to P = 16384)
+    ('loss_step.hip', 'assign_compact2_kernel'): 2,
+    ('loss_step.hip', 'assign_resolve2_kernel'): 2,
+    ('loss_step.hip', 'assign_topk2_kernel'): 2,
 }
 FILES = ['api.hip', 'conv_fwd.hip', 'conv_fwd16.hip', 'conv_fwd64.hip', 'conv_bwd.hip', 'conv_bwd16.hip', 'conv_stem.hip',
          'loss_step.hip']
