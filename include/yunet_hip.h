@@ -210,7 +210,8 @@ typedef struct YunetLevels {
  * _bbox_decode (yunet_head.py:376-386) + SimOTAAssigner._assign
  * (core/bbox/assigners/sim_ota_assigner.py:95-257, bbox_overlaps
  * core/bbox/iou_calculators/iou2d_calculator.py:232-253) + PseudoSampler, three launches: compaction
- * of the valid priors per image, top-k per (image, GT) pair, conflict resolution per image.
+ * of the valid priors, top-k per (image, GT) pair, conflict resolution per image (two interchangeable sets of launches:
+ * option "assign_v2" below; identical outputs).
  * flat [N,P,16] = cls | dx dy dw dh | obj | 10 kps.
  * gt_boxes [N,Gmax,4] xyxy, gt_kps [N,Gmax,5,3] (x,y,vis), gt_labels [N,Gmax] or NULL,
  * gt_count [N].  Outputs: gt_inds [N,P] int32 (1-based, 0 = background),
@@ -455,6 +456,10 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *                        p[5] -> yunet_stem_bwd_rz) as matrix products on the matrix cores | 0: the VALU tile kernels
  *   "bwd32_split"        1 (default): the 32 -> 64 backward unit (YuNet_s) on the split-bf16 matrix path | 0: exact-fp32 MFMA
  *   "upadd_coarse"       1 (default): yunet_upadd_bwd with dxa = NULL on the dedicated coarse-gradient kernel | 0: general kernel
+ *   "assign_v2"          1 (default): yunet_assign* on the round-5 launches (compaction per 256-prior chunk, one workgroup per
+ *                        (image, GT) pair with a candidate-pruned walk, one wave per conflict; needs Gmax < P, N <= 65535) | 0: one
+ *                        workgroup per image for compaction / conflicts, every pair evaluated in full.  Same outputs, bit for bit.
+ *   "fwd_group"          1 (default): yunet_dp_fwd_group puts independent plain 64 -> 64 units into one grid | 0: one launch each
  *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 600 000; env YUNET_ONESHOT_TIMEOUT_MS)
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
