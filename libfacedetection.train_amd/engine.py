@@ -418,6 +418,7 @@ class Plan:
                       i=[n, self.P, gmax, int(arch.get('candidate_topk', 10))],
                       f=[arch['center_radius'], float(arch.get('iou_weight', 3.0)), float(arch.get('cls_weight', 1.0))])
         op.lv = self.levels
+        self.assign_idx = len(self.fwd_a)
         self.fwd_a.append(op)
         self.fwd_a.append(self._op(L.OP_LOSS_NORM, p=[self.img_stats.data_ptr(),
                                                      self.norm.data_ptr()],
@@ -501,6 +502,8 @@ class Plan:
         fin_def.p[4] = self.dy_norm.data_ptr()
         self.c_fwd_b_loss = self._carray([loss_def])
         self.c_fwd_b_rest = self._carray([fin_def] + self.fwd_b[2:])
+        self.own_gt = (self.gt_boxes, self.gt_kps, self.gt_count)     # the plan's own staging buffers (bind_gt)
+        self._gt_bound = tuple(t.data_ptr() for t in self.own_gt)
 
         # ---- world > 1: the same backward in TWO segments so that the gradient all-reduce of the
         # first bucket (head, neck and the backbone stages from the first pyramid tap on: the tail
@@ -786,6 +789,24 @@ class Plan:
         self.bwd_nodes.append((self._lane, bwd, self._join_before))
         return out
 
+    def bind_gt(self, boxes, kps, count):
+        """Point the assignment and loss ops at padded GT tensors ([N,Gmax,4] fp32, [N,Gmax,5,3] fp32, [N] int32, contiguous, on
+        this device) -- the plan's own staging buffers, or the data source's when it delivers them in this layout
+        (synthetic.GTList / the device input pipeline): the step then reads them in place, like the image, instead of copying
+        them first (three copy kernels with ~10 us between them in front of every step, profiles/r05_trace_gaps.json).  The
+        tensors stay referenced here until the next bind."""
+        ptrs = (boxes.data_ptr(), kps.data_ptr(), count.data_ptr())
+        self.gt_boxes, self.gt_kps, self.gt_count = boxes, kps, count
+        if ptrs == self._gt_bound:
+            return
+        a = self.c_fwd_a[self.assign_idx]
+        assert a.opcode == L.OP_ASSIGN
+        a.p[1], a.p[2], a.p[4] = ptrs
+        for arr in (self.c_fwd_b, self.c_fwd_b_loss):
+            assert arr[0].opcode == L.OP_LOSS
+            arr[0].p[3], arr[0].p[4] = ptrs[0], ptrs[1]
+        self._gt_bound = ptrs
+
     def set_img(self, img):
         ptr = img.data_ptr()
         for which, idx in self.img_ptr_ops:
@@ -836,10 +857,20 @@ class YuNetEngine:
         pb, pk = getattr(gt_bboxes, 'padded', None), getattr(gt_keypointss, 'padded', None)
         if pb is not None and pk is not None and pb.shape[1] == plan.gmax and pb.is_cuda:
             # fast path: the data source already padded the GT (synthetic.GTList)
+            cnt = gt_bboxes.counts
+            own_b, own_k, own_c = plan.own_gt
+            if (not os.environ.get('YUNET_COPY_GT') and pb.device == own_b.device and cnt.device == own_b.device and
+                    pk.device == own_b.device and pb.dtype == torch.float32 and pk.dtype == torch.float32 and
+                    cnt.dtype == torch.int32 and pb.is_contiguous() and pk.is_contiguous() and cnt.is_contiguous() and
+                    tuple(pb.shape) == tuple(own_b.shape) and pk.numel() == own_k.numel() and cnt.numel() == n):
+                plan.bind_gt(pb, pk, cnt)          # read in place (no copy kernels in front of the step)
+                return
+            plan.bind_gt(*plan.own_gt)
             plan.gt_boxes.copy_(pb, non_blocking=True)
-            plan.gt_kps.copy_(pk, non_blocking=True)
-            plan.gt_count.copy_(gt_bboxes.counts, non_blocking=True)
+            plan.gt_kps.copy_(pk.reshape(own_k.shape), non_blocking=True)
+            plan.gt_count.copy_(cnt, non_blocking=True)
             return
+        plan.bind_gt(*plan.own_gt)
         cnt_t = getattr(gt_bboxes, 'counts', None)
         if cnt_t is not None:
             # a GTList whose padded companion does not fit this plan (other Gmax / host-resident):
@@ -1122,6 +1153,7 @@ class YuNetEngine:
         self.plan = plan
         self._img = img          # the backward op list reads the image again (stem wgrad)
         plan.set_img(img)
+        plan.bind_gt(*plan.own_gt)       # (never zero a data source's tensor)
         plan.gt_count.zero_()
         self._exec(plan.c_fwd_a, 'yunet_exec(fwd_a)')
         return plan.flat
