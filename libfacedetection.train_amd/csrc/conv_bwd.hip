@@ -1074,6 +1074,23 @@ __device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
             (__attribute__((address_space(3))) unsigned char*)p));
     return __builtin_bit_cast(u32x2, v);
 }
+// bf16 activation storage (YUNET_ACT_BF16): the forward of this mode multiplied
+// bf16(a) with bf16(W1) (conv_fwd64.hip), so the backward that is consistent with it recomputes p as that ONE product,
+// takes dW1 = bf16(a)^T dp as two (dp = hi + lo) and da = dp bf16(W1) as two: 5 matrix products per tile instead of 9,
+// and the low plane of `a` is neither written nor read
+// (round 5; -DYUNET_BWD64_BF16_LEAN=0 builds the earlier variant, which split the fp32 a and W1 as the fp32 build does:
+// same-box A/B of the bf16 step 4.00 -> 3.89 ms, profiles/r05_bf16_lean_ab.log)
+#ifndef YUNET_BWD64_BF16_LEAN
+#define YUNET_BWD64_BF16_LEAN 1
+#endif
+#if defined(YUNET_ACT_BF16) && YUNET_BWD64_BF16_LEAN
+#define BWD64_LEAN 1
+#else
+#define BWD64_LEAN 0
+#endif
+__device__ __forceinline__ f32x4 mfma1r(const u32x4 a, const u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x4 mfma3r(const u32x4 ah, const u32x4 al, const u32x4 bh, const u32x4 bl, f32x4 c) {
     const bf16x8 xh = __builtin_bit_cast(bf16x8, ah), xl = __builtin_bit_cast(bf16x8, al);
     const bf16x8 yh = __builtin_bit_cast(bf16x8, bh), yl = __builtin_bit_cast(bf16x8, bl);
@@ -1546,7 +1563,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                        tin(xv.w, i_mean.w, i_scale.w, i_beta.w, relu_floor), h1, l1);
                 unsigned char* ap = s_a + plane_off(ip, och4 >> 1) + (och4 & 1) * 8;
                 *reinterpret_cast<u32x2*>(ap) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(ap + PLANE) = u32x2{l0, l1};
+                if (!BWD64_LEAN) *reinterpret_cast<u32x2*>(ap + PLANE) = u32x2{l0, l1};
             }
         }
         __syncthreads();
@@ -1569,10 +1586,11 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 for (int mi = 0; mi < 4; ++mi) {
                     const unsigned char* ap = abase + mi * 16 * (C * 2) + (((4 * kb + go) ^ sw) << 4);
                     ah[mi] = *reinterpret_cast<const u32x4*>(ap);
-                    al[mi] = *reinterpret_cast<const u32x4*>(ap + PLANE);
+                    if (!BWD64_LEAN) al[mi] = *reinterpret_cast<const u32x4*>(ap + PLANE);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[mi] = BWD64_LEAN ? mfma1r(ah[mi], w1h[kb], acc[mi]) : mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             float* pw = s_p + (mh * 64 + 4 * go) * C + nt * 16 + l15o;
@@ -1694,15 +1712,23 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     const unsigned char* a1 = s_a + plane_off(p0 + 8, chA) + (sub & 1) * 8;
                     const unsigned char* b0 = s_d + plane_off(p0, chB) + (sub & 1) * 8;
                     const unsigned char* b1 = s_d + plane_off(p0 + 8, chB) + (sub & 1) * 8;
-                    const u32x2 ah0 = tr_read(a0), ah1 = tr_read(a1), al0 = tr_read(a0 + PLANE), al1 = tr_read(a1 + PLANE);
+                    const u32x2 ah0 = tr_read(a0), ah1 = tr_read(a1);
+                    u32x2 al0 = u32x2{0, 0}, al1 = u32x2{0, 0};
+                    if (!BWD64_LEAN) { al0 = tr_read(a0 + PLANE); al1 = tr_read(a1 + PLANE); }
                     const u32x2 bh0 = tr_read(b0), bh1 = tr_read(b1), bl0 = tr_read(b0 + PLANE), bl1 = tr_read(b1 + PLANE);
                     ah[tI] = u32x4{ah0.x, ah0.y, ah1.x, ah1.y}; al[tI] = u32x4{al0.x, al0.y, al1.x, al1.y};
                     bh[tI] = u32x4{bh0.x, bh0.y, bh1.x, bh1.y}; bl[tI] = u32x4{bl0.x, bl0.y, bl1.x, bl1.y};
                 }
+                if (BWD64_LEAN) {      // a = its bf16 plane: a^T (dp_lo) then a^T (dp_hi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        gw1[q] = mfma1r(ah[q >> 1], bh[q & 1], mfma1r(ah[q >> 1], bl[q & 1], gw1[q]));
+                } else {
                 gw1[0] = mfma3r(ah[0], al[0], bh[0], bl[0], gw1[0]);
                 gw1[1] = mfma3r(ah[0], al[0], bh[1], bl[1], gw1[1]);
                 gw1[2] = mfma3r(ah[1], al[1], bh[0], bl[0], gw1[2]);
                 gw1[3] = mfma3r(ah[1], al[1], bh[1], bl[1], gw1[3]);
+                }
             }
         }
         DP_BWD64_STAMP(3);
@@ -1730,7 +1756,9 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                         pl[mi] = *reinterpret_cast<const u32x4*>(q + PLANE);
                     }
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) da[mi] = mfma3r(ph[mi], pl[mi], wth[kb], wtl[kb], da[mi]);
+                    for (int mi = 0; mi < 4; ++mi)
+                        da[mi] = BWD64_LEAN ? mfma1r(ph[mi], wth[kb], mfma1r(pl[mi], wth[kb], da[mi]))
+                                            : mfma3r(ph[mi], pl[mi], wth[kb], wtl[kb], da[mi]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
