@@ -41,7 +41,11 @@ sub = {}
 ms, fr, _ = fam('dp_bwd64_kernel'); sub['BWD64_MS'], sub['BWD64_FRAC'] = f'{ms:.2f}', f'{fr:.2f}'
 sub['BWD64_80'], sub['BWD64_40'] = inst('dp_bwd64_kernel<8,false,false>'), inst('dp_bwd64_kernel<4,false,false>')
 sub['BWD64_P'], sub['BWD64_S'] = inst('dp_bwd64_kernel<8,false,true>'), inst('dp_bwd64_kernel<8,true,false>')
-ms, fr, _ = fam('dp_fwd64s_kernel'); sub['FWD64_MS'], sub['FWD64_FRAC'] = f'{ms:.2f}', f'{fr:.2f}'
+ms, fr, n1 = fam('dp_fwd64s_kernel')
+ms2, fr2, n2 = fam('dp_fwd64s_group_kernel')          # the three share convs in one grid (same body)
+sub['FWD64_MS'] = f'{ms + ms2:.2f}'
+sub['FWD64_FRAC'] = f'{(fr * ms + fr2 * ms2) / (ms + ms2):.2f}' if ms + ms2 else 'n/a'
+sub['FWD64_N'] = str(n1 + n2)
 ms, fr, _ = fam('dp_bwd16s_kernel'); sub['BWD16_MS'], sub['BWD16_FRAC'] = f'{ms:.2f}', f'{fr:.2f}'
 ms, fr = tile_bwd(); sub['BWDT_MS'], sub['BWDT_FRAC'] = f'{ms:.2f}', f'{fr:.2f}'
 ms, fr, _ = fam('dp_fwd16s_kernel'); sub['FWD16_MS'], sub['FWD16_FRAC'] = f'{ms:.2f}', f'{fr:.2f}'
