@@ -393,23 +393,25 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve_kernel(
 }
 
 // ===== round 5: the same three steps, balanced over the chip (option assign_v2, default) ==============================
-// What the launches above cost at the bench batch (256 images, WIDER's faces-per-image histogram: 3 % of the images
-// carry 64 faces): 53 + 63 + 39 us, and none of it is memory traffic -- every one of them is the dependent chain of its
+// What the launches above cost at the bench batch (256 images, WIDER's faces-per-image histogram: 5 % of the images
+// carry 64 faces): 53 + 61 + 39 us, and none of it is memory traffic -- every one of them is the dependent chain of its
 // slowest wave.  `compact` and `resolve` run ONE workgroup per image whose chain grows with the image's face count (a
 // thread loops over every GT), so the launch lasts as long as the most crowded image while the other CUs idle; `topk`
 // evaluates the full cost (division, logarithm, two 10-deep insertion networks: ~200 dependent instructions) for every
 // (valid prior, GT) pair although a GT can only ever select priors whose box it overlaps or whose centre lies in its
 // box-and-centre region, fetches one record per round trip to memory, and merges the per-lane lists with reductions
 // built from LDS permutes.  Here
-//   A2  compacts per CHUNK of 256 priors (grid = images x chunks) with FOUR threads per prior, each looping over a quarter
+//   A2  compacts per CHUNK of 256 priors (grid = images x chunks) with CQ = 2 threads per prior, each looping over half
 //       of the GTs: valid priors of chunk c occupy the slots 256 c .. 256 c + vc[n][c] - 1 of the image's work arrays --
 //       ascending prior index, so "lowest slot" is still "lowest prior index" in every tie;
-//   B2  (one workgroup = four GTs of one image, one wave each) stages the image's records in blocks of 512 through LDS,
-//       the next block's loads in flight under the current block's arithmetic; a wave spends ~60 instructions per pair
-//       on the overlap / region tests, compacts the pairs that can matter into a per-wave list and runs the expensive
-//       part on those alone (exactness: see the kernel); wave reductions on the DPP row operations;
+//   B2  (one workgroup of four waves per (image, GT) pair, pairs from a dense list A2 writes) stages the image's records in
+//       blocks of 512 through LDS, the next block's loads in flight under the current block's arithmetic; a wave spends
+//       ~60 instructions per prior on the overlap / region tests, compacts the priors that can matter into a per-wave
+//       list and runs the expensive part on those alone (exactness: see the kernel); wave reductions on the DPP row
+//       operations; the four waves' lists are merged through LDS;
 //   C2  resolves each conflict with a whole wave (one GT per lane) instead of one lane looping over every GT.
-// Outputs are bit-identical to the launches above (tests/test_loss_step_gpu.py runs both).
+// Outputs are bit-identical to the launches above (tests/test_loss_step_gpu.py runs both).  Measured (profiles/
+// r05_assign_kernels.log): A2 24 us, B2 61 us (11 fixed + 12 walk + 8 evaluation + 28 list merges), C2 13 us.
 #define CCH 256                      // priors per chunk of A2
 #define CCH_SHIFT 8
 #ifndef A2_CQ
@@ -474,7 +476,7 @@ __device__ __forceinline__ int wave_sum_i_dpp(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// ---- A2: one workgroup per (image, chunk of 256 priors), four threads per prior -------------------------------------------
+// ---- A2: one workgroup per (image, chunk of 256 priors), CQ threads per prior ---------------------------------------------
 __global__ __launch_bounds__(CCH * CQ) void assign_compact2_kernel(
     const float* __restrict__ flat, const float* __restrict__ gt_boxes, const int32_t* __restrict__ gt_count,
     Levels L, int P, int Gmax, float radius, int nchunk, int32_t* __restrict__ gt_inds, int32_t* __restrict__ labels,
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(CCH * CQ) void assign_compact2_kernel(
     const float* __restrict__ pre_boxes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GT* s_gt = reinterpret_cast<GT*>(smem);
-    constexpr int NWV = CCH * CQ / 64;                            // 16 waves, 16 priors each
+    constexpr int NWV = CCH * CQ / 64;                            // waves of the workgroup, 64 / CQ priors each
     __shared__ int s_wcnt[NWV];
     const int n = blockIdx.x / nchunk, c = blockIdx.x - n * nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
