@@ -54,3 +54,14 @@ def test_ctypes_structs_match_c_layout(tmp_path):
             C.sizeof(L.YunetLossCfg), L.YunetOp.p.offset, L.YunetOp.bn.offset, L.YunetOp.dp.offset,
             L.YunetOp.lv.offset, L.YunetDP.prof.offset, C.sizeof(L.YunetComm), L.YunetComm.status.offset]
     assert got == want
+
+
+def test_op_list_constants_match_the_header():
+    """The op-list conventions the Python plan builder relies on (lane / group slots of YunetOp.i, group size, lane count)
+    are the header's."""
+    import yunet_amd._lib as L
+    txt = open(HEADER).read()
+    defs = {k: int(v) for k, v in re.findall(r'#define\s+(YUNET_\w+)\s+(\d+)\s', txt)}
+    assert defs['YUNET_OP_LANE'] == L.OP_LANE and defs['YUNET_MAX_LANES'] == L.MAX_LANES
+    assert defs['YUNET_OP_GROUP'] == L.OP_GROUP and defs['YUNET_DP_GROUP_MAX'] == L.DP_GROUP_MAX
+    assert L.OP_GROUP != L.OP_LANE and L.OP_GROUP < 11        # i[11] carries the activation storage type
