@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YUNET_ABI_VERSION 10
+#define YUNET_ABI_VERSION 11
 
 #define YUNET_EINVAL (-1)   /* bad argument / unsupported channel count */
 #define YUNET_EOPCODE (-2)  /* unknown opcode in an op list            */
@@ -460,7 +460,7 @@ int yunet_aug_pixels(const uint8_t* src, const long long* src_off, const int32_t
  *                        (image, GT) pair with a candidate-pruned walk, one wave per conflict; needs Gmax < P, N <= 65535) | 0: one
  *                        workgroup per image for compaction / conflicts, every pair evaluated in full.  Same outputs, bit for bit.
  *   "fwd_group"          1 (default): yunet_dp_fwd_group puts independent plain 64 -> 64 units into one grid | 0: one launch each
- *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 600 000; env YUNET_ONESHOT_TIMEOUT_MS)
+ *   "oneshot_timeout_ms" how long yunet_allreduce waits for a peer (default 120 000; env YUNET_ONESHOT_TIMEOUT_MS)
  * "no_pack" and "bwd64_nw" change yunet_dp_bwd_blocks(): set them before any plan is built.
  * Returns the previous value, or YUNET_EINVAL for an unknown name / a value out of range. */
 int yunet_set_option(const char* name, int value);
@@ -478,16 +478,19 @@ int yunet_set_option(const char* name, int value);
  * 64-byte handles over any host channel -> yunet_comm_open on every peer's handle -> fill a YunetComm.
  * Every rank must issue the same sequence of yunet_allreduce calls on a given YunetComm (one YunetComm per stream
  * that carries collectives).  A peer that never arrives makes the wait give up after option "oneshot_timeout_ms"
- * (default 600 000 = 10 min, the order of the process group's own time-out): yunet_comm_status() then returns the
+ * (default 120 000 = 2 min: a step lasts milliseconds, a peer that is two minutes late is gone): yunet_comm_status() then returns the
  * sequence number of that call and the buffer is POISONED with NaN (the shares of the blocks that gave up), so a
  * caller that never reads the status word cannot train on un-reduced gradients unnoticed. */
 #define YUNET_MAX_RANKS 8
 #define YUNET_IPC_HANDLE_BYTES 64
+/* bytes in front of the message slots of an inbox (ABI 11: flags per (parity, rank, piece) + the local send counter;
+ * messages above 64 KB travel as 2 / 4 / 8 pieces, one workgroup per peer and piece) */
+#define YUNET_COMM_HEADER_BYTES 20480
 typedef struct YunetComm {
     int32_t rank, world;
     uint32_t seq;                    /* calls made so far; incremented by yunet_allreduce (start at 0)          */
     int32_t reserved_;
-    uint64_t slot_bytes;             /* capacity of one message: (inbox bytes - 4096) / (2 * world)            */
+    uint64_t slot_bytes;             /* capacity of one message: (inbox bytes - YUNET_COMM_HEADER_BYTES) / (2 * world) */
     void* inbox[YUNET_MAX_RANKS];    /* inbox of rank r as mapped into THIS process (own rank: the allocation) */
     int32_t* status;                 /* HOST word from yunet_comm_alloc                                        */
 } YunetComm;

@@ -65,7 +65,7 @@ class YunetAugCfg(C.Structure):
                 ('max_attempts', C.c_int32), ('max_retries', C.c_int32), ('gmax', C.c_int32)]
 
 
-MAX_RANKS, IPC_HANDLE_BYTES = 8, 64
+MAX_RANKS, IPC_HANDLE_BYTES, COMM_HEADER_BYTES = 8, 64, 20480
 
 
 class YunetComm(C.Structure):
@@ -176,7 +176,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yunet_abi_version() != 10:
+    if lib.yunet_abi_version() != 11:
         raise YunetHipError('libyunet_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

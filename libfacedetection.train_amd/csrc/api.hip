@@ -142,7 +142,7 @@ YunetOptions& yunet_options() {
         v.bwd32_split = env("YUNET_BWD32_SPLIT", 1);
         v.assign_v2 = env("YUNET_ASSIGN_V2", 1);
         v.fwd_group = env("YUNET_FWD_GROUP", 1);
-        v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 600000);
+        v.oneshot_timeout_ms = env("YUNET_ONESHOT_TIMEOUT_MS", 120000);
         if (v.bwd64_nw != 4 && v.bwd64_nw != 8) v.bwd64_nw = 0;
         if (v.ew_grid < 1) v.ew_grid = 768;
         return v;

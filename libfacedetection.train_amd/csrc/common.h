@@ -242,7 +242,7 @@ struct YunetOptions {
     int assign_v2;           // 1 (default): the SimOTA assignment on the chunk-balanced / candidate-pruned launches
                              // (loss_step.hip, round 5); 0: one workgroup per image + full evaluation of every pair
     int oneshot_timeout_ms;  // how long yunet_allreduce waits for a peer before it poisons the buffer and sets the status
-                             // word (default 600 000 = 10 min, the process group's order of magnitude; tests use 1 000)
+                             // word (default 120 000 = 2 min; tests use 1 000)
 };
 YunetOptions& yunet_options();
 int yunet_option_assign_v2();      // (for loss_step.hip, which does not include this header)

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_compact_kernel(
 
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = min(gt_count[n], Gmax);
+    const int G = max(0, min(gt_count[n], Gmax));      // (a negative count from an unvalidated data source is an empty image)
     const float* fl = flat + (size_t)n * P * 16;
     VRec* rec_out = ws.rec + (size_t)n * P;
     int* cnt = ws.cnt + (size_t)n * P;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(TOPK_WAVES * 64) void assign_topk_kernel(
     const int n = blockIdx.x / gblocks;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = (blockIdx.x - n * gblocks) * TOPK_WAVES + wid;
-    const int G = min(gt_count[n], Gmax);
+    const int G = max(0, min(gt_count[n], Gmax));      // (a negative count from an unvalidated data source is an empty image)
     const int V = ws.V[n];
     if (g >= G || V <= 0) return;                 // wave-uniform
     const VRec* __restrict__ rec = ws.rec + (size_t)n * P;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve_kernel(
     __shared__ float s_red[ASSIGN_WAVES][2];
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = min(gt_count[n], Gmax);
+    const int G = max(0, min(gt_count[n], Gmax));      // (a negative count from an unvalidated data source is an empty image)
     const int V = ws.V[n];
     const VRec* __restrict__ rec = ws.rec + (size_t)n * P;
     const int* cnt = ws.cnt + (size_t)n * P;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(CCH * CQ) void assign_compact2_kernel(
     const int n = blockIdx.x / nchunk, c = blockIdx.x - n * nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = tid & (CQ - 1);
-    const int G = min(gt_count[n], Gmax);
+    const int G = max(0, min(gt_count[n], Gmax));      // (a negative count from an unvalidated data source is an empty image)
     const int p = c * CCH + tid / CQ;
     const bool lead = q == 0 && p < P;                            // the thread that decodes and stores prior p
     // the prior's head outputs go in flight before anything else (only valid priors use them)
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(CCH * CQ) void assign_compact2_kernel(
         // images before it
         const int N = gridDim.x / nchunk;
         int part = 0;
-        for (int i = tid; i < n; i += CCH * CQ) part += min(gt_count[i], Gmax);
+        for (int i = tid; i < n; i += CCH * CQ) part += max(0, min(gt_count[i], Gmax));
         part = wave_sum_i_dpp(part);
         if (lane == 0) s_wcnt[wid] = part;
         __syncthreads();
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_resolve2_kernel(
     __shared__ int s_nconf;
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = min(gt_count[n], Gmax);
+    const int G = max(0, min(gt_count[n], Gmax));      // (a negative count from an unvalidated data source is an empty image)
     const VRec* __restrict__ rec = ws.rec + (size_t)n * P;
     const int* cnt = ws.cnt + (size_t)n * P;
     const uint16_t* vidx = ws.vidx + (size_t)n * P;

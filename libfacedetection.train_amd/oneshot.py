@@ -67,7 +67,7 @@ class OneShotAllReduce:
             with torch.cuda.device(self.device):
                 comm = L.YunetComm()
                 comm.rank, comm.world, comm.seq = self.rank, self.world, 0
-                comm.slot_bytes = (nbytes - 4096) // (2 * self.world)
+                comm.slot_bytes = (nbytes - L.COMM_HEADER_BYTES) // (2 * self.world)
                 comm.status = self._status
                 for r, (_, h, _) in enumerate(reports):
                     if r == self.rank:

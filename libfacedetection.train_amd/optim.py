@@ -67,6 +67,13 @@ class FusedSGD:
     @torch.no_grad()
     def step(self, closure=None):
         eng = self._bind()
+        if getattr(eng, '_os_main', None) is not None or getattr(eng, '_os_side', None) is not None:
+            # opt-in one-shot all-reduce: a peer that never arrived left NaN in the gradient and a status word on the
+            # host.  Find out BEFORE the update is applied (and before an after_train_iter CheckpointHook could save the
+            # poisoned parameters as "the last checkpoint"): wait for this step's collectives, then read the words
+            # (costs the launch overlap of one step, only on this path)
+            torch.cuda.current_stream(eng.device).synchronize()
+            eng._check_oneshot()
         g = self.param_groups[0]
         if self._lr_val != g['lr']:
             self._lr_dev.fill_(float(g['lr']))

@@ -10,10 +10,32 @@ scalars travel as a single 5-float message.  BatchNorm statistics stay per-rank
 (no SyncBN; broadcast_buffers=False in the reference).
 """
 import os
+import re
 
-import torch
-import torch.distributed as dist
-import torch.nn as nn
+# dmabuf IPC (RCCL / peer-mapped inboxes across processes): the runtime reads this when it initialises, so it is set when
+# this module is imported -- tools/train.py imports it before anything touches the GPU -- not inside init_dist (ADVICE r5)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+
+def first_slurm_host(nodelist):
+    """First host of a SLURM node list without scontrol: 'node[01-04,07],gpu3' -> 'node01', 'a,b' -> 'a'.  Nested or
+    multi-dimensional bracket forms raise (better than handing torch.distributed an unparsed 'node[01-04]')."""
+    m = re.match(r'^([^,\[\]]+)(?:\[([^\]]+)\])?([^,\[\]]*)', nodelist.strip())
+    if not m or not m.group(1):
+        raise ValueError(f'cannot take the first host of SLURM node list {nodelist!r}; set MASTER_ADDR')
+    prefix, ranges, suffix = m.group(1), m.group(2), m.group(3)
+    if ranges is None:
+        return prefix
+    if '[' in suffix or ']' in suffix:
+        raise ValueError(f'cannot take the first host of SLURM node list {nodelist!r}; set MASTER_ADDR')
+    first = ranges.split(',')[0].split('-')[0]
+    if not first.isdigit():
+        raise ValueError(f'cannot take the first host of SLURM node list {nodelist!r}; set MASTER_ADDR')
+    return prefix + first + suffix
 
 
 def launcher_env(launcher, env=None, first_host=None):
@@ -35,13 +57,17 @@ def launcher_env(launcher, env=None, first_host=None):
                     import subprocess
                     try:
                         return subprocess.check_output(['scontrol', 'show', 'hostname', n], text=True).split()[0]
-                    except Exception:          # noqa: BLE001 -- no scontrol: a plain host name works as is
-                        return n.split(',')[0]
+                    except Exception:          # noqa: BLE001 -- no scontrol: expand the bracket form here
+                        return first_slurm_host(n)
             out['MASTER_ADDR'] = first_host(nodes)
     elif launcher == 'mpi':
         out['RANK'] = str(int(env['OMPI_COMM_WORLD_RANK']))
         out['WORLD_SIZE'] = str(int(env['OMPI_COMM_WORLD_SIZE']))
         out['LOCAL_RANK'] = str(int(env.get('OMPI_COMM_WORLD_LOCAL_RANK', 0)))
+        if 'MASTER_ADDR' not in env:
+            # mmcv's _init_dist_mpi raises KeyError here too: a multi-node job that fell back to 127.0.0.1 would
+            # rendezvous every node with itself
+            raise KeyError('MASTER_ADDR: the mpi launcher needs the address of rank 0 in the environment')
     elif launcher != 'pytorch':
         raise ValueError(f'Invalid launcher type: {launcher}')
     if 'MASTER_ADDR' not in env and 'MASTER_ADDR' not in out:
@@ -59,7 +85,6 @@ def init_dist(launcher='pytorch', backend='nccl', **kwargs):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', rank))
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / peer-mapped inboxes across processes
     if backend == 'nccl' and torch.cuda.is_available():
         dev = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
         torch.cuda.set_device(dev)

@@ -31,11 +31,20 @@ class LrSchedule:
     POLICIES = ('step', 'fixed', 'exp', 'poly', 'inv', 'CosineAnnealing')
 
     def __init__(self, base_lr, step=None, gamma=0.1, warmup=None, warmup_iters=0, warmup_ratio=0.1, policy='step',
-                 by_epoch=True, min_lr=None, min_lr_ratio=None, power=1.0, **_):
+                 by_epoch=True, min_lr=None, min_lr_ratio=None, power=1.0, warmup_by_epoch=False, **unknown):
         if policy not in self.POLICIES:
             raise NotImplementedError(f'lr policy {policy!r}: implemented are {self.POLICIES}')
         if warmup not in (None, 'constant', 'linear', 'exp'):
-            raise ValueError(f'"{warmup}" is not a supported type for warming up, valid types are "constant" and "linear"')
+            raise ValueError(f'"{warmup}" is not a supported type for warming up, valid types are "constant", "linear" '
+                             f'and "exp"')
+        # an option this restatement does not implement must not be swallowed: the schedule would silently differ from
+        # mmcv's
+        if warmup_by_epoch:
+            raise NotImplementedError('lr_config: warmup_by_epoch=True is not implemented (warm-up runs by iteration)')
+        if unknown:
+            raise NotImplementedError(f'lr_config: unsupported option(s) {sorted(unknown)} for policy {policy!r}')
+        if policy == 'step' and isinstance(gamma, (list, tuple)):
+            raise NotImplementedError('lr_config: a per-step gamma list is not implemented')
         if policy == 'step' and step is None:
             raise ValueError('lr policy "step" needs step=<int | list>')
         if policy == 'CosineAnnealing' and (min_lr is None) == (min_lr_ratio is None):

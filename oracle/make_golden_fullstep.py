@@ -6,7 +6,7 @@ tests/test_fullsize_gpu.py::test_full_step_vs_oracle compares the HIP step with 
 full-batch oracle steps on the GPU box's host while the GPU lease idles (380 - 860 s of a 90-minute budget, VERDICT r3
 weak #7 / next #4).
 
-    python oracle/make_golden_fullstep.py [n:320:256:11:init ...]      (no arguments: the four test cases)
+    python oracle/make_golden_fullstep.py [n:320:256:11:init ...]      (no arguments: the six test cases)
 
 Per case (inputs are regenerated in the test from the same seeds: synthetic.make_batch, oracle.init_state / the
 trained fixture):
@@ -40,7 +40,18 @@ import yunet_oracle as O  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 TRAINED = os.path.join(GOLDEN, 'yunet_n_synth_trained.pth')
-CASES = [('n', 320, 256, 11, 'init'), ('n', 640, 64, 12, 'init'), ('s', 320, 512, 13, 'init'), ('n', 320, 256, 14, 'trained')]
+
+
+def trained_path(kind):
+    """The trained-checkpoint-like fixture of an architecture (tools/make_trained_fixture.py); YuNet is fully
+    convolutional, so the 320 x 320 fixture also drives the 640 x 640 configuration (as in bench.py: run_other_config)."""
+    return os.path.join(GOLDEN, f'yunet_{kind}_synth_trained.pth')
+
+
+# the three BASELINE batches from random initialisation + the three configurations bench.py TIMES (trained fixtures on
+# structured faces: SimOTA with dynamic_k 7-9 and real conflicts) -- VERDICT r5 next 3
+CASES = [('n', 320, 256, 11, 'init'), ('n', 640, 64, 12, 'init'), ('s', 320, 512, 13, 'init'), ('n', 320, 256, 14, 'trained'),
+         ('n', 640, 64, 15, 'trained'), ('s', 320, 512, 16, 'trained')]
 STRIDE = 41            # priors kept in the samples: flat[:, ::41, :]
 
 
@@ -48,7 +59,7 @@ def case_inputs(kind, h, n, seed, weights):
     arch = O.yunet_arch(kind)
     if weights == 'trained':
         sd = {k: v.float() if v.is_floating_point() else v
-              for k, v in torch.load(TRAINED, map_location='cpu', weights_only=False)['state_dict'].items()}
+              for k, v in torch.load(trained_path(kind), map_location='cpu', weights_only=False)['state_dict'].items()}
     else:
         sd = O.init_state(arch, seed=seed)
     b = S.make_batch(n, h, h, seed, structured=weights == 'trained')

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} is declared in include/yunet_hip.h but not exported'
     assert sorted(L.EXPORTED) == names, 'ctypes signature table and header disagree'
-    assert lib.yunet_abi_version() == 10
+    assert lib.yunet_abi_version() == 11
     assert lib.yunet_conv_blocks() >= 256
     assert lib.yunet_loss_blocks(256, 2100) >= 1
 
@@ -65,3 +65,7 @@ def test_op_list_constants_match_the_header():
     assert defs['YUNET_OP_LANE'] == L.OP_LANE and defs['YUNET_MAX_LANES'] == L.MAX_LANES
     assert defs['YUNET_OP_GROUP'] == L.OP_GROUP and defs['YUNET_DP_GROUP_MAX'] == L.DP_GROUP_MAX
     assert L.OP_GROUP != L.OP_LANE and L.OP_GROUP < 11        # i[11] carries the activation storage type
+    assert defs['YUNET_MAX_RANKS'] == L.MAX_RANKS and defs['YUNET_IPC_HANDLE_BYTES'] == L.IPC_HANDLE_BYTES
+    assert defs['YUNET_COMM_HEADER_BYTES'] == L.COMM_HEADER_BYTES        # one-shot inbox: flags + counter before the slots
+    lib = L.load()
+    assert lib.yunet_comm_inbox_bytes(4, 1000) == L.COMM_HEADER_BYTES + 2 * 4 * 1024

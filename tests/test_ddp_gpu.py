@@ -178,6 +178,60 @@ def test_two_gpus_rccl_if_available():
     assert res['n_gpus'] == 2 and res['dist']['backend'] == 'nccl' and len(res['per_rank_images_per_sec']) == 2
 
 
+def _free_port_cli():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """bench.py's N > 1 code on EVERY 1-GPU box: two ranks share the card over a gloo process group --
+    the bucketed window with its per-collective timing, then the SAME window through the one-shot all-reduce (self-check,
+    peer time-out cap, watchdog).  A functional check of the rank code the driver's scaling run executes, not a scaling
+    number (profiles/r05_two_rank_one_gpu.log was this command run by hand)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YUNET_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port_cli()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6',
+           '--warmup', '3', '--batch', '64']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'rank 0 must print ONE JSON line, got {len(lines)}'
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['steps'] >= 6 and res['value'] > 0
+    assert res['dist']['backend'] == 'gloo' and len(res['per_rank_images_per_sec']) == 2
+    comm = res['dist']['comm_ms_per_step']
+    assert {'num_pos', 'bucket_a', 'bucket_b', 'wait_a'} <= set(comm), comm
+    one = res['dist']['oneshot']
+    assert one.get('status') == 0, one
+    assert one['value'] > 0 and {'num_pos', 'bucket_a', 'bucket_b', 'wait_a'} <= set(one['comm_ms_per_step'])
+
+
+def test_dist_train_sh_two_ranks_over_gloo(tmp_path):
+    """tools/dist_train.sh (the reference's launcher line, tools/dist_train.sh:11-21) end to end: 2 ranks sharing the card over
+    gloo, 3 iterations of YuNet_s through tools/train.py --launcher pytorch; the ranks must end with IDENTICAL parameters
+    (the point of the gradient all-reduce) and rank 0 writes the checkpoint."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS='2', YUNET_DUMP_PARAM_SUM=str(tmp_path))
+    cmd = [os.path.join(root, 'tools', 'dist_train.sh'), os.path.join(root, 'configs', 'yunet_s.py'), '2',
+           str(_free_port_cli()), '--work-dir', str(tmp_path), '--max-iters', '3', '--no-validate', '--cfg-options',
+           'dist_params.backend=gloo', 'data.samples_per_gpu=16', 'data.train.iters_per_epoch=3',
+           'checkpoint_config.interval=1', 'log_config.interval=1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    sums = sorted(f for f in os.listdir(tmp_path) if f.startswith('param_sum_rank'))
+    assert len(sums) == 2, os.listdir(tmp_path)
+    a, b = (open(os.path.join(tmp_path, f)).read() for f in sums)
+    assert a == b and float(a.split()[0]) == float(a.split()[0]), (a, b)            # identical on both ranks, finite
+    assert any(f.endswith('.pth') for f in os.listdir(tmp_path)), os.listdir(tmp_path)
+
+
 def test_ddp_through_device_pipeline_keeps_gt_counts():
     """the DDP scatter used to rebuild GT lists as plain lists, so a DeviceGT's padded
     zero rows became fake faces.  Train one step through pipelines.DevicePipeline behind the DDP

@@ -137,7 +137,10 @@ def _avail_gb():
 TRAINED = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'yunet_n_synth_trained.pth')
 
 
-FULLSTEP = [c + ('init',) for c in CONFIGS] + [('n', 320, 256, 14, 'trained')]
+# the three BASELINE batches from random initialisation, plus the three configurations bench.py TIMES: trained fixtures on
+# structured faces (headline n-320 bs 256; other_configs n-640 bs 64 and s-320 bs 512)
+FULLSTEP = [c + ('init',) for c in CONFIGS] + [('n', 320, 256, 14, 'trained'), ('n', 640, 64, 15, 'trained'),
+                                                ('s', 320, 512, 16, 'trained')]
 
 
 def _load_fullstep(kind, h, n, weights):
@@ -279,7 +282,8 @@ def _full_step_vs_live_oracle(kind, h, n, seed, weights):
     arch = O.yunet_arch(kind)
     if weights == 'trained':
         sd = {k: v.float() if v.is_floating_point() else v
-              for k, v in torch.load(TRAINED, map_location='cpu', weights_only=False)['state_dict'].items()}
+              for k, v in torch.load(TRAINED.replace('yunet_n_', f'yunet_{kind}_'), map_location='cpu',
+                                     weights_only=False)['state_dict'].items()}
     else:
         sd = O.init_state(arch, seed=seed)
     model.load_state_dict(sd, strict=True)

@@ -66,7 +66,21 @@ def test_launcher_env_mapping():
     assert launcher_env('slurm', env=dict(e, MASTER_ADDR='x', MASTER_PORT='5'), first_host=None) == \
         {'RANK': '11', 'WORLD_SIZE': '16', 'LOCAL_RANK': '3'}
     # mpi
-    got = launcher_env('mpi', env={'OMPI_COMM_WORLD_RANK': '1', 'OMPI_COMM_WORLD_SIZE': '2', 'OMPI_COMM_WORLD_LOCAL_RANK': '1'})
-    assert got['RANK'] == '1' and got['WORLD_SIZE'] == '2' and got['LOCAL_RANK'] == '1'
+    mpi = {'OMPI_COMM_WORLD_RANK': '1', 'OMPI_COMM_WORLD_SIZE': '2', 'OMPI_COMM_WORLD_LOCAL_RANK': '1'}
+    got = launcher_env('mpi', env=dict(mpi, MASTER_ADDR='head'))
+    assert got['RANK'] == '1' and got['WORLD_SIZE'] == '2' and got['LOCAL_RANK'] == '1' and 'MASTER_ADDR' not in got
+    with pytest.raises(KeyError):          # as mmcv's _init_dist_mpi: no silent 127.0.0.1 for a multi-node job
+        launcher_env('mpi', env=mpi)
     with pytest.raises(ValueError):
         launcher_env('ssh', env={})
+
+
+def test_first_slurm_host_without_scontrol():
+    from yunet_amd.parallel import first_slurm_host
+    assert first_slurm_host('node[01-04]') == 'node01'
+    assert first_slurm_host('node[07,09-12],gpu3') == 'node07'
+    assert first_slurm_host('a,b') == 'a' and first_slurm_host('gpu3') == 'gpu3'
+    assert first_slurm_host('rack[2-3]n') == 'rack2n'
+    for bad in ('', '[1-2]', 'n[a-b]'):
+        with pytest.raises(ValueError):
+            first_slurm_host(bad)

@@ -188,3 +188,14 @@ def test_runner_runs_a_cosine_schedule(tmp_path):
     assert len(lrs) == 12 and r.max_iters == 12
     for it, lr in enumerate(lrs):
         assert lr == pytest.approx(0.5 * 0.01 * (math.cos(math.pi * it / 12) + 1))
+
+
+def test_lr_config_rejects_what_it_does_not_implement():
+    """An lr_config key this restatement ignores would give a different schedule than mmcv without a word."""
+    from yunet_amd.runner import LrSchedule
+    LrSchedule(0.01, policy='step', step=[2, 4], warmup='exp', warmup_iters=3, warmup_ratio=0.1, warmup_by_epoch=False)
+    for bad in (dict(warmup_by_epoch=True), dict(periods=[1, 2]), dict(cyclic_times=3), dict(gamma=[0.1, 0.5])):
+        with pytest.raises(NotImplementedError):
+            LrSchedule(0.01, policy='step', step=[2, 4], **bad)
+    with pytest.raises(ValueError, match='"exp"'):
+        LrSchedule(0.01, policy='step', step=1, warmup='cosine')

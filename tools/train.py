@@ -136,8 +136,17 @@ def main(argv=None):
     model.init_weights()
     ds = build_source(cfg, rank, world, args.seed if args.seed is not None else 0)
     meta = dict(config=cfg.pretty_text, seed=seed, exp_name=os.path.basename(args.config), CLASSES=('face',))
-    return R.train_detector(model, ds, cfg, distributed=distributed, validate=not args.no_validate,
+    hist = R.train_detector(model, ds, cfg, distributed=distributed, validate=not args.no_validate,
                             timestamp=timestamp, meta=meta, max_iters=args.max_iters)
+    dump = os.environ.get('YUNET_DUMP_PARAM_SUM')
+    if dump:
+        # launcher tests: every rank leaves a checksum of its parameters (data-parallel ranks must end identical)
+        with torch.no_grad():
+            flat = torch.cat([p.detach().double().reshape(-1) for p in model.parameters()])
+            text = f'{float(flat.sum())!r} {float(flat.abs().sum())!r} {float((flat * flat).sum())!r}'
+        with open(os.path.join(dump, f'param_sum_rank{rank}.txt'), 'w') as f:
+            f.write(text)
+    return hist
 
 
 if __name__ == '__main__':
