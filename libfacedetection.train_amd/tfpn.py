@@ -1,7 +1,7 @@
 """TFPN neck parameter container (interface of mmdet/models/necks/tfpn.py:8-45): one
 ConvDPUnit(c, c) per input level under `lateral_convs`, top-down nearest-neighbour 2x
-upsample-add from the coarsest level.  As with the backbone, training runs inside the engine;
-`forward` is the stand-alone path.
+upsample-add from the coarsest level.  As with the backbone, the YuNet detector's step runs inside the engine;
+`forward` is the stand-alone, differentiable path (necks/tfpn.py:33-45).
 """
 import torch.nn as nn
 

@@ -1,8 +1,9 @@
 """YuNetBackbone parameter container (interface of mmdet/models/backbones/yunet_backbone.py:8-41:
 same constructor arguments, same child names model0 .. model{L-1}, so checkpoints load strictly).
 
-Training does not call `forward` here -- the detector's engine runs the whole conv stack from the
-flat parameter buffer.  `forward` is the stand-alone feature path used by feature_test / tests.
+The YuNet detector's training step does not call `forward` here -- its engine runs the whole conv stack from the
+flat parameter buffer.  `forward` is the stand-alone path: differentiable (one autograd node per unit, functional.py),
+so a foreign neck / head can train through this backbone as through the reference's (yunet_backbone.py:33-41).
 """
 import torch.nn as nn
 

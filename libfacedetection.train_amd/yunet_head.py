@@ -10,6 +10,7 @@ directly.
 import torch
 import torch.nn as nn
 
+from . import functional as Fh
 from . import kernels as K
 from .builder import HEADS, build_assigner, build_loss, build_prior_generator, build_sampler
 from .registry import ConfigDict
@@ -134,10 +135,11 @@ class YuNet_Head(nn.Module):
         yunet_init_weights(self)
 
     # ------------------------------------------------------------------ stand-alone forward
-    @torch.no_grad()
     def forward(self, feats):
         """NCHW feature maps -> (cls_preds, bbox_preds, obj_preds, kps_preds) lists of NCHW
-        maps (yunet_head.py:175-247), via ONE fused 64->16 HIP unit per level."""
+        maps (yunet_head.py:175-247), via ONE fused 64->16 HIP unit per level.  Differentiable (functional.py: one
+        autograd node per ConvDPUnit; the four per-level heads share a node, torch.cat splits its weight gradient):
+        `forward` + `loss` is a complete training path outside the fused engine."""
         feats = list(feats)
         if self.shared_stack_convs > 0:
             feats = [convs(f) for f, convs in zip(feats, self.multi_level_share_convs)]
@@ -145,21 +147,14 @@ class YuNet_Head(nn.Module):
         for l, f in enumerate(feats):
             units = (self.multi_level_cls[l], self.multi_level_bbox[l], self.multi_level_obj[l],
                      self.multi_level_kps[l])
-
-            def fused(x):
-                c = x.shape[1]
-                w1 = torch.cat([u.conv1.weight.detach().reshape(-1, c) for u in units]).contiguous()
-                b1 = torch.cat([u.conv1.bias.detach() for u in units]).contiguous()
-                w2 = torch.cat([u.conv2.weight.detach().reshape(-1, 9) for u in units]).contiguous()
-                b2 = torch.cat([u.conv2.bias.detach() for u in units]).contiguous()
-                return K.dp_fwd(x.float().permute(0, 2, 3, 1).contiguous(), w1, b1, w2, b2).permute(0, 3, 1, 2)
             if self.stacked_convs > 0:
-                # towers (yunet_head.py:191-207): cls from the cls tower, bbox / obj / kps from the reg tower; this
-                # inference helper runs the fused 64 -> 16 unit on both and keeps each tower's own channels
-                zc, zr = fused(self.multi_level_cls_convs[l](f)), fused(self.multi_level_reg_convs[l](f))
+                # towers (yunet_head.py:191-207): cls from the cls tower, bbox / obj / kps from the reg tower; the fused
+                # 64 -> 16 unit runs on both and each tower keeps its own channels
+                zc = Fh.fused_dp_units(units, self.multi_level_cls_convs[l](f))
+                zr = Fh.fused_dp_units(units, self.multi_level_reg_convs[l](f))
                 z = torch.cat([zc[:, 0:1], zr[:, 1:]], 1)
             else:
-                z = fused(f)
+                z = Fh.fused_dp_units(units, f)
             for o, (a, b) in zip(outs, ((0, 1), (1, 5), (5, 6), (6, 16))):
                 o.append(z[:, a:b].contiguous())
         return outs

@@ -1,10 +1,11 @@
 """Parameter containers of the YuNet blocks, with the reference's class / attribute names
 (mmdet/models/utils/yunet_layer.py:4-82; tools/yunet2cpp.py:102-126 walks these names).
 
-The arithmetic does not live here: in training the detector's fused engine reads the
-parameters from one flat buffer these modules' tensors are views of.  `forward` is a
-stand-alone, no-autograd path (feature extraction / inference) built from the same HIP
-kernels.
+Inside the YuNet detector the arithmetic does not live here: the fused engine reads the
+parameters from one flat buffer these modules' tensors are views of.  `forward` is the
+stand-alone path, differentiable like the reference modules (functional.py: one
+torch.autograd.Function per unit on yunet_dp_fwd / yunet_dp_bwd and yunet_stem_*), so any other
+detector can train through these blocks.
 """
 import torch
 import torch.nn as nn
