@@ -1026,6 +1026,20 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
 #ifndef YUNET_BWD64_ADDR2
 #define YUNET_BWD64_ADDR2 1
 #endif
+// Round 6: the two fp32 tiles the matrix-layout phases touch with 4-byte accesses (p / dx writes, x reads of the mask) are
+// XOR-swizzled: a wave's 32-lane group there is 16 channels x 2 pixel groups 4 pixels apart = 256 words = the SAME banks
+// (every such access paid a 2-way conflict); element (pixel, channel) now lives at channel ^ 16 * ((pixel >> 2) & 1).  The
+// row-wise 16-byte accesses of the stage / depthwise / store phases see a wave-uniform flip (a wave's four pixels share
+// pixel bit 2), so nothing else changes.  -DYUNET_BWD64_SWZ=0 = the linear layout.
+#ifndef YUNET_BWD64_SWZ
+#define YUNET_BWD64_SWZ 1
+#endif
+#ifndef YUNET_BWD64_PFMODE      // measurement switch: 1 = the next tile's loads issued at once (after the p GEMM)
+#define YUNET_BWD64_PFMODE 0
+#endif
+namespace bwd64 {
+__device__ __forceinline__ int tile_swz(int pixel) { return YUNET_BWD64_SWZ ? ((pixel >> 2) & 1) << 4 : 0; }
+}
 namespace bwd64 {
 constexpr int C = 64, C4 = 16;
 constexpr int PLANE_PX = 128;      // (pixels of the largest tile: plane_off() only needs the row pitch)
@@ -1044,10 +1058,11 @@ struct Geo {
     static constexpr int REM_HP0 = NDZ * PSTEP;                        // first halo pixel of the remainder
     static constexpr int NX = (IP * C4) / NT;                          // x float4 per thread
     static constexpr int PLANE = IP * C * 2;                           // one bf16 plane
+    static constexpr int XP = C;                                       // floats per pixel of the fp32 tiles s_x / s_p
     static constexpr int OFF_DZ = 0;                                   // float [HP][64]; later dp planes hi | lo
-    static constexpr int OFF_X = OFF_DZ + HP * C * 4;                  // float [IP][64] raw x
-    static constexpr int OFF_P = OFF_X + IP * C * 4;                   // float [IP][64] p, later the masked dx
-    static constexpr int OFF_A = OFF_P + IP * C * 4;                   // bf16 planes hi | lo of a = T(x)
+    static constexpr int OFF_X = OFF_DZ + HP * C * 4;                  // float [IP][XP] raw x
+    static constexpr int OFF_P = OFF_X + IP * XP * 4;                  // float [IP][XP] p, later the masked dx
+    static constexpr int OFF_A = OFF_P + IP * XP * 4;                  // bf16 planes hi | lo of a = T(x)
     static constexpr int WORKB = OFF_A + 2 * PLANE;
     static constexpr int PAR_F = 9 * C + 7 * C + 5 * C + C;            // w2 | out-bn | in-bn | b1 (floats)
     static constexpr int MH = NW / 4;                                  // pixel halves (p / da GEMM: 4 pixel tiles per wave)
@@ -1109,7 +1124,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     constexpr bool ADDR2 = !PACKED && (YUNET_BWD64_ADDR2 != 0);      // round 5: shift-only halo addressing (issue2)
     constexpr int NT = G::NT, TH = G::TH, TW = G::TW, HW_ = G::HW_, HP = G::HP, IP = G::IP, NDZ = G::NDZ, NX = G::NX;
     constexpr int PSTEP = G::PSTEP, PLANE = G::PLANE, OFF_DZ = G::OFF_DZ, OFF_X = G::OFF_X, OFF_P = G::OFF_P;
-    constexpr int OFF_A = G::OFF_A, WORKB = G::WORKB, KSPLIT = G::KSPLIT, MH = G::MH;
+    constexpr int OFF_A = G::OFF_A, WORKB = G::WORKB, KSPLIT = G::KSPLIT, MH = G::MH, XP = G::XP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* s_dz = reinterpret_cast<float*>(smem_raw + OFF_DZ);
     float* s_x = reinterpret_cast<float*>(smem_raw + OFF_X);
@@ -1555,7 +1570,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             for (int i = 0; i < NX; ++i) {
                 const int ip = hp0 + PSTEP * i;
                 const float4 xv = act_unpack(px[i]);
-                *reinterpret_cast<float4*>(s_x + ip * C + och4 * 4) = xv;
+                *reinterpret_cast<float4*>(s_x + ip * XP + ((och4 * 4) ^ tile_swz(hp0))) = xv;
                 unsigned h0, l0, h1, l1;
                 split2(tin(xv.x, i_mean.x, i_scale.x, i_beta.x, relu_floor),
                        tin(xv.y, i_mean.y, i_scale.y, i_beta.y, relu_floor), h0, l0);
@@ -1593,12 +1608,12 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     acc[mi] = BWD64_LEAN ? mfma1r(ah[mi], w1h[kb], acc[mi]) : mfma3r(ah[mi], al[mi], w1h[kb], w1l[kb], acc[mi]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float* pw = s_p + (mh * 64 + 4 * go) * C + nt * 16 + l15o;
+            float* pw = s_p + (mh * 64 + 4 * go) * XP + ((nt * 16 + l15o) ^ tile_swz(4 * go));
             if (tile_full) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * C] = acc[mi][r] + bias1;
+                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * XP] = acc[mi][r] + bias1;
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
@@ -1606,7 +1621,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     for (int r = 0; r < 4; ++r) {
                         const int ip = (mh * 4 + mi) * 16 + 4 * go + r;
                         const bool in = inside(ip, y0 + ip / TW, x0 + ip % TW);
-                        pw[(mi * 16 + r) * C] = in ? acc[mi][r] + bias1 : 0.0f;
+                        pw[(mi * 16 + r) * XP] = in ? acc[mi][r] + bias1 : 0.0f;
                     }
             }
         }
@@ -1615,7 +1630,11 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         // next tile's loads go out in four pieces from here on (the p GEMM above runs with no load in flight: a
         // CU cannot keep a whole tile's 124 KB in flight, and the in-order vector-memory queue would hold any
         // scratch access behind them)
+#if YUNET_BWD64_PFMODE == 1     // experiment: the whole next tile at once
+        if (more) issue_any(t + gridDim.x, All{});
+#else
         if (more) issue_any(t + gridDim.x, std::integral_constant<int, 0>{});
+#endif
 
         // ---- depthwise backward on the VALU (sliding window over a 4-row column); dp stays in registers -------------
         float4 dp[4];
@@ -1626,12 +1645,12 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             const int vtx = pg % TW, vr0 = (pg / TW) * 4;
             d_pix0 = vr0 * TW + vtx;
             const float* zb = s_dz + (vr0 * HW_ + vtx) * C + cq * 4;
-            const float* pb = s_p + (vr0 * TW + vtx) * C + cq * 4;
+            const float* pb = s_p + (vr0 * TW + vtx) * XP + ((cq * 4) ^ tile_swz(vtx));
             const float* wb = s_w2 + cq * 4;
             float4 pv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pv[r] = *reinterpret_cast<const float4*>(pb + r * TW * C);
+                pv[r] = *reinterpret_cast<const float4*>(pb + r * TW * XP);
                 dp[r] = make_float4(0, 0, 0, 0);
             }
             if (!(abl & 2)) {
@@ -1673,7 +1692,9 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 gb1.x += dp[r].x; gb1.y += dp[r].y; gb1.z += dp[r].z; gb1.w += dp[r].w;
             }
         }
+#if YUNET_BWD64_PFMODE != 1
         if (more) issue_any(t + gridDim.x, std::integral_constant<int, 1>{});
+#endif
         __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
         {
             const int cq = opaque((int)threadIdx.x) % C4;
@@ -1690,7 +1711,9 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
         __syncthreads();
         DP_BWD64_STAMP(2);
+#if YUNET_BWD64_PFMODE != 1
         if (more) issue_any(t + gridDim.x, std::integral_constant<int, 2>{});
+#endif
 
         // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
         // k index of lane group G, element e (0..7): pixel 32 kb + 4 * (4 (G >> 1) + 2 (e >> 2) + (G & 1)) + (e & 3) --
@@ -1732,7 +1755,9 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
         DP_BWD64_STAMP(3);
+#if YUNET_BWD64_PFMODE != 1
         if (more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
+#endif
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
         // Everything a step needs is requested before the step that consumes it (operands of both k blocks, then the
@@ -1765,13 +1790,13 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             if (bn_in) {
                 const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
                 const float m_lo = s_ci[4 * C + c];
-                const float* xrd = s_x + (mh * 64 + 4 * go) * C + c;
-                float* pw = s_p + (mh * 64 + 4 * go) * C + c;
+                const float* xrd = s_x + (mh * 64 + 4 * go) * XP + (c ^ tile_swz(4 * go));
+                float* pw = s_p + (mh * 64 + 4 * go) * XP + (c ^ tile_swz(4 * go));
                 float xr[4][4];
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xr[mi][r] = xrd[(mi * 16 + r) * C];
+                    for (int r = 0; r < 4; ++r) xr[mi][r] = xrd[(mi * 16 + r) * XP];
                 if (!tile_full) {
                     // a pixel outside the image carries dp = 0, hence da = 0: only the mask of the BN sums is at
                     // stake, and da = 0 contributes nothing to them either -- but keep x finite and masked
@@ -1791,7 +1816,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                         const float v = fmaf(xr[mi][r] - m_mean, m_scale, m_beta) > 0.0f ? da[mi][r] : 0.0f;   // ReLU mask
                         t0 += v;
                         t1 = fmaf(v, bn_center(xr[mi][r], m_mean, m_lo) * m_inv, t1);
-                        pw[(mi * 16 + r) * C] = v;
+                        pw[(mi * 16 + r) * XP] = v;
                     }
                 // 64 pixels per lane in fp32 (a handful of terms), folded over the four lane groups; then fp64 for the
                 // long, heavily cancelling accumulation over the whole tensor
@@ -1803,11 +1828,11 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     bs[C] += (double)t1;
                 }
             } else {
-                float* pw = s_p + (mh * 64 + 4 * go) * C + c;
+                float* pw = s_p + (mh * 64 + 4 * go) * XP + (c ^ tile_swz(4 * go));
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * C] = da[mi][r];
+                    for (int r = 0; r < 4; ++r) pw[(mi * 16 + r) * XP] = da[mi][r];
             }
         }
         __syncthreads();
@@ -1840,7 +1865,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     const int ip = tid / C4 + PSTEP * i;
-                    float4 v = *reinterpret_cast<const float4*>(s_p + ip * C + ich4 * 4);
+                    float4 v = *reinterpret_cast<const float4*>(s_p + ip * XP + ((ich4 * 4) ^ tile_swz(ip)));
                     const float4 o = *reinterpret_cast<const float4*>(&old[i]);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
@@ -1849,7 +1874,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     const int ip = tid / C4 + PSTEP * i;
-                    const float4 v = *reinterpret_cast<const float4*>(s_p + ip * C + ich4 * 4);
+                    const float4 v = *reinterpret_cast<const float4*>(s_p + ip * XP + ((ich4 * 4) ^ tile_swz(ip)));
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
                 }
             }

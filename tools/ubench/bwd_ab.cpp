@@ -298,7 +298,7 @@ int main(int argc, char** argv) {
             YunetDP d;
             memset(&d, 0, sizeof(d));
             d.N = N; d.H = H; d.W = W; d.cin = ci; d.cout = co;
-            d.in_transform = YUNET_T_BNRELU; d.out_has_bn = 1; d.accumulate_dx = 0;
+            d.in_transform = YUNET_T_BNRELU; d.out_has_bn = getenv("NOBN") ? 0 : 1; d.accumulate_dx = 0;      // NOBN: no z read
             d.x_img_stride = (int64_t)H * W * ci; d.z_img_stride = (int64_t)H * W * co;
             d.x = dx_x;
             d.in_bn = YunetBN{dsin, dbsi, dgi, dbi, (int32_t)px, 1e-5f, slots};
