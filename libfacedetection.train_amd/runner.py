@@ -102,31 +102,48 @@ class SyntheticWiderFace:
     RetinaFaceDataset + the cv2 pipeline, which need the WIDER images (out of scope)."""
 
     def __init__(self, img_scale=(640, 640), samples_per_gpu=16, iters_per_epoch=403, rank=0,
-                 max_gt=synthetic.MAX_GT, **_):
+                 max_gt=synthetic.MAX_GT, resident=0, **_):
         self.h, self.w = img_scale[1], img_scale[0]
         self.bs, self.iters_per_epoch, self.rank, self.max_gt = \
             samples_per_gpu, iters_per_epoch, rank, max_gt
+        # resident = k > 0: k batches are generated once, kept on the device and cycled (what bench.py feeds: the step
+        # with inputs already in HBM); 0: a fresh batch is drawn on the host every iteration
+        self.resident, self._pool = int(resident), {}
 
     def batch(self, it, device=None):
+        if self.resident > 0 and device is not None:
+            k = it % self.resident
+            if k not in self._pool:
+                b = synthetic.make_batch(self.bs, self.h, self.w, synthetic.batch_seed(self.rank, k), self.max_gt)
+                self._pool[k] = synthetic.to_device(b, device)
+            return self._pool[k]
         b = synthetic.make_batch(self.bs, self.h, self.w, synthetic.batch_seed(self.rank, it),
                                  self.max_gt)
         return synthetic.to_device(b, device) if device is not None else b
 
 
 class SyntheticSourceImages:
-    """Synthetic DECODED sources (uint8 HWC at WIDER-like sizes, ragged GT) kept resident on the
-    device and pushed through the reference's train pipeline on the GPU (pipelines.DevicePipeline:
-    RandomSquareCrop -> Resize -> RandomFlip -> collate) every iteration -- the role of
-    RetinaFaceDataset + the cv2 worker processes, minus image decoding."""
+    """Synthetic DECODED sources (uint8 HWC at WIDER-like sizes, ragged GT) pushed through the reference's train
+    pipeline on the GPU (pipelines.DevicePipeline: RandomSquareCrop -> Resize -> RandomFlip -> collate) every iteration
+    -- the role of RetinaFaceDataset + the cv2 worker processes, minus image decoding.
+
+    host_fed=False: the decoded sources stay resident in HBM (WIDER-Face train, 12 880 images, is ~30 GB decoded: it
+    fits 288 GB many times over), an iteration costs the two pipeline launches.
+    host_fed=True : the sources live in PINNED HOST memory and every iteration's batch is uploaded on a copy stream into
+    one of two device buffers while the previous step runs (what a host data loader has to pay: the decoded uint8
+    source of an image is 1 - 2.4 MB, more than its 320 x 320 fp32 crop).  `timing=True` records events around the
+    upload and the pipeline (`report()`)."""
 
     def __init__(self, pipeline, samples_per_gpu=16, iters_per_epoch=403, rank=0, pool=64,
                  src_hw=((768, 1024), (1024, 683), (500, 375), (683, 1024)), max_gt=synthetic.MAX_GT,
-                 seed=0, **_):
+                 seed=0, host_fed=False, timing=False, **_):
         from .pipelines import DevicePipeline
         self.pipe = DevicePipeline(pipeline, seed=seed + 7919 * rank, gmax=64 if max_gt <= 64 else 128)
         self.bs, self.iters_per_epoch, self.rank = samples_per_gpu, iters_per_epoch, rank
         self.pool, self.src_hw, self.max_gt, self.seed = pool, src_hw, max_gt, seed
+        self.host_fed, self.timing = bool(host_fed), bool(timing)
         self._src = None
+        self._ev = []
 
     def _build(self, device):
         import numpy as np
@@ -142,14 +159,90 @@ class SyntheticSourceImages:
             kps.append(k[0])
         idx = [i % self.pool for i in range(self.bs)]
         return SourceBatch.from_lists([imgs[i] for i in idx], [boxes[i] for i in idx],
-                                      [kps[i] for i in idx], device)
+                                      [kps[i] for i in idx], 'cpu' if self.host_fed else device)
+
+    def _build_host_fed(self, device):
+        """Pinned host copy of the batch's sources + two device buffers + the copy stream."""
+        from .pipelines import SourceBatch
+        host = self._build(device)
+        self._host_src = host.src.pin_memory()
+        meta = [t.to(device) for t in (host.src_off, host.src_hw, host.boxes, host.kps, host.gt_off)]
+        self._bufs = [torch.empty_like(self._host_src, device=device) for _ in range(2)]
+        self._views = [SourceBatch(b, *meta) for b in self._bufs]
+        self._copy = torch.cuda.Stream(device=device)
+        self._uploaded = [None, None]          # event: buffer b holds iteration's sources
+        self._consumed = [None, None]          # event: the pipeline that read buffer b has run
+        self._pending = {}
+
+    def _upload(self, it):
+        b = it % 2
+        with torch.cuda.stream(self._copy):
+            if self._consumed[b] is not None:
+                self._copy.wait_event(self._consumed[b])
+            e0 = torch.cuda.Event(enable_timing=self.timing)
+            e0.record(self._copy)
+            self._bufs[b].copy_(self._host_src, non_blocking=True)
+            e1 = torch.cuda.Event(enable_timing=self.timing)
+            e1.record(self._copy)
+        self._uploaded[b] = e1
+        self._pending[it] = (e0, e1)
 
     def batch(self, it, device=None):
         if device is None:
             raise RuntimeError('SyntheticSourceImages augments on the GPU: a device is required')
+        cur = torch.cuda.current_stream()
+        if not self.host_fed:
+            if self._src is None:
+                self._src = self._build(device)
+            # (the two pipeline launches on a side stream under the previous step were measured: 4.96 -> 4.98 ms per
+            #  iteration, nothing -- the step's persistent kernels fill the GPU, the pipeline's 0.31 ms is work, not latency)
+            p0 = self._mark(cur)
+            out = self.pipe(self._src, it)
+            if self.timing:
+                self._ev.append((None, (p0, self._mark(cur))))
+            return out
         if self._src is None:
-            self._src = self._build(device)
-        return self.pipe(self._src, it)
+            self._src = True
+            self._build_host_fed(device)
+        if it not in self._pending:
+            self._upload(it)
+        b = it % 2
+        h2d = self._pending.pop(it)
+        cur.wait_event(self._uploaded[b])
+        p0 = self._mark(cur)
+        out = self.pipe(self._views[b], it)
+        done = torch.cuda.Event(enable_timing=self.timing)
+        done.record(cur)
+        self._consumed[b] = done
+        if self.timing:
+            self._ev.append((h2d, (p0, done)))
+        self._upload(it + 1)                   # the next batch travels while this step runs
+        return out
+
+    def _mark(self, stream):
+        if not self.timing:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def report(self, skip=5):
+        """Mean milliseconds per batch of the upload and of the two pipeline launches (timing=True; synchronises)."""
+        if not self.timing:
+            return {}
+        torch.cuda.synchronize()
+        ev = self._ev[skip:]
+        out = {'batches_timed': len(ev)}
+        h = [a.elapsed_time(b) for (hd, _) in ev if hd is not None for a, b in [hd]]
+        p = [a.elapsed_time(b) for (_, (a, b)) in ev if a is not None]
+        if h:
+            out['h2d_ms'] = sum(h) / len(h)
+            out['h2d_bytes'] = int(self._host_src.numel())
+            out['h2d_GBs'] = out['h2d_bytes'] / (out['h2d_ms'] * 1e-3) / 1e9
+        if p:
+            out['pipeline_ms'] = sum(p) / len(p)
+        self._ev = []
+        return out
 
 
 def save_checkpoint(model, optimizer, path, meta):

@@ -149,3 +149,23 @@ def test_device_pipeline_feeds_train_step_full_batch():
     torch.cuda.synchronize()
     loss = float(out['log_vars']['loss'])
     assert loss == loss and 0 < loss < 1e4
+
+
+def test_host_fed_sources_equal_resident_sources():
+    """runner.SyntheticSourceImages(host_fed=True): the batch's decoded sources live in pinned host memory and travel on a
+    copy stream into one of two device buffers under the previous step -- the pipeline's outputs must be bit-identical to
+    the resident mode's for every iteration (double-buffer hand-over, events), and `report()` carries the upload timing."""
+    import yunet_amd
+    import yunet_amd.runner as R
+    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'yunet_s.py'))
+    kw = dict(samples_per_gpu=12, pool=5, seed=3, src_hw=((300, 420), (512, 384), (200, 200)))
+    a = R.SyntheticSourceImages(cfg.train_pipeline, **kw)
+    b = R.SyntheticSourceImages(cfg.train_pipeline, host_fed=True, timing=True, **kw)
+    for it in range(5):
+        ba, bb = a.batch(it, 'cuda'), b.batch(it, 'cuda')
+        torch.cuda.synchronize()
+        assert torch.equal(ba['img'], bb['img']), it
+        assert torch.equal(ba['gt_bboxes'].padded, bb['gt_bboxes'].padded) and torch.equal(ba['gt_bboxes'].counts, bb['gt_bboxes'].counts)
+        assert torch.equal(ba['gt_keypointss'].padded, bb['gt_keypointss'].padded)
+    rep = b.report(skip=0)
+    assert rep['batches_timed'] == 5 and rep['h2d_ms'] > 0 and rep['pipeline_ms'] > 0 and rep['h2d_bytes'] > 12 * 200 * 200 * 3 - 1

@@ -135,6 +135,7 @@ def main(argv=None):
     model = yunet_amd.build_detector(cfg.model)
     model.init_weights()
     ds = build_source(cfg, rank, world, args.seed if args.seed is not None else 0)
+    main.last_source = ds                      # (measurement tools read the source's own timing: tools/train_e2e.py)
     meta = dict(config=cfg.pretty_text, seed=seed, exp_name=os.path.basename(args.config), CLASSES=('face',))
     hist = R.train_detector(model, ds, cfg, distributed=distributed, validate=not args.no_validate,
                             timestamp=timestamp, meta=meta, max_iters=args.max_iters)
