@@ -155,9 +155,11 @@ def test_host_fed_sources_equal_resident_sources():
     """runner.SyntheticSourceImages(host_fed=True): the batch's decoded sources live in pinned host memory and travel on a
     copy stream into one of two device buffers under the previous step -- the pipeline's outputs must be bit-identical to
     the resident mode's for every iteration (double-buffer hand-over, events), and `report()` carries the upload timing."""
+    import os
     import yunet_amd
     import yunet_amd.runner as R
-    cfg = yunet_amd.Config.fromfile(os.path.join(ROOT, 'configs', 'yunet_s.py'))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yunet_amd.Config.fromfile(os.path.join(root, 'configs', 'yunet_s.py'))
     kw = dict(samples_per_gpu=12, pool=5, seed=3, src_hw=((300, 420), (512, 384), (200, 200)))
     a = R.SyntheticSourceImages(cfg.train_pipeline, **kw)
     b = R.SyntheticSourceImages(cfg.train_pipeline, host_fed=True, timing=True, **kw)
