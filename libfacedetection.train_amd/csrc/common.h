@@ -56,6 +56,19 @@ __device__ __forceinline__ act_raw4 act_pack(const float4 v) {
     return act_raw4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
 #endif
 }
+// Cache policy of the big streaming stores: bit 1 = "nt" (non-temporal) on gfx950.  Round 6, same-box alternations of bench.py
+// (profiles/r06_bench_ab_nt*.log): the dx stores of the BACKWARD units on the unpacked maps (>= 40 x 40: 105 MB - 1 GB per
+// tensor, nothing of it survives in a cache until its consumer runs) are better kept out of the 4 MB L2 of their XCD, where
+// they push out the halo rows the neighbouring tiles are about to re-read: dp_bwd64 -1.5 .. -3 %, step -0.5 %.  The forward
+// units' z stores are NOT: on the 40 x 40 and smaller maps the next forward kernel finds them in the L2 / infinity cache, and
+// with nt the ten plain 64 -> 64 forward launches got 4 % slower.  YUNET_ST_AUX: forward stores (default policy);
+// YUNET_DX_AUX: backward dx stores on unpacked maps.
+#ifndef YUNET_ST_AUX
+#define YUNET_ST_AUX 0
+#endif
+#ifndef YUNET_DX_AUX
+#define YUNET_DX_AUX 2
+#endif
 // 4 consecutive channels through a buffer descriptor (byte offset; out-of-range offsets read 0 / drop)
 template <typename R>
 __device__ __forceinline__ act_raw4 act_bufld4(R rsrc, unsigned byte_off) {
@@ -65,12 +78,21 @@ __device__ __forceinline__ act_raw4 act_bufld4(R rsrc, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
 #endif
 }
+// the same load with cache-policy bits (AUX = 2: non-temporal -- a tensor a kernel reads exactly once)
+template <int AUX, typename R>
+__device__ __forceinline__ act_raw4 act_bufld4_aux(R rsrc, unsigned byte_off) {
+#ifdef YUNET_ACT_BF16
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, AUX);
+#else
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, AUX);
+#endif
+}
 template <typename R>
 __device__ __forceinline__ void act_bufst4(R rsrc, unsigned byte_off, const float4 v) {
 #ifdef YUNET_ACT_BF16
-    __builtin_amdgcn_raw_buffer_store_b64(act_pack(v), rsrc, byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(act_pack(v), rsrc, byte_off, 0, YUNET_ST_AUX);
 #else
-    __builtin_amdgcn_raw_buffer_store_b128(act_pack(v), rsrc, byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(act_pack(v), rsrc, byte_off, 0, YUNET_ST_AUX);
 #endif
 }
 // the same through plain pointers (element-wise kernels)

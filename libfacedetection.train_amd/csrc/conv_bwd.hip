@@ -886,14 +886,14 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                     float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
                     const float4 o = *reinterpret_cast<const float4*>(&old[i]);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, PACKED ? 0 : YUNET_DX_AUX);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < G::NX; ++i) {
                     const int ip = (tid + BWD_THREADS * i) / G::C4I;
                     const float4 v = *reinterpret_cast<const float4*>(s_a + ip * G::LSI + ich4 * 4);
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, PACKED ? 0 : YUNET_DX_AUX);
                 }
             }
         }
@@ -1033,6 +1033,13 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
 // pixel bit 2), so nothing else changes.  -DYUNET_BWD64_SWZ=0 = the linear layout.
 #ifndef YUNET_BWD64_SWZ
 #define YUNET_BWD64_SWZ 1
+#endif
+#ifndef YUNET_BWD64_X_AUX        // cache-policy bits of the x loads of the unpacked instances: x is read exactly once (tile interior only),
+                                 // non-temporal keeps it out of the L2 the dy / z halo re-reads live in (step -0.04 ms, profiles/r06_bench_ab_ntx.log)
+#define YUNET_BWD64_X_AUX 2
+#endif
+#ifndef YUNET_BWD64_DY_AUX       // cache-policy bits of the dy loads (measurement switch; 0 = default policy; the dx stores: common.h YUNET_DX_AUX)
+#define YUNET_BWD64_DY_AUX 0
 #endif
 #ifndef YUNET_BWD64_PFMODE      // measurement switch: 1 = the next tile's loads issued at once (after the p GEMM)
 #define YUNET_BWD64_PFMODE 0
@@ -1317,7 +1324,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
                 pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
             } else {
-                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dybytes, 0, 0);
+                const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dybytes, 0, YUNET_BWD64_DY_AUX);
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
             }
             pz[i] = act_raw4{};
@@ -1372,7 +1379,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const bool ok = tfull || (y0 + 2 * i + r < H && x0 + hxm < W);
-                px[i] = act_bufld4(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes);
+                px[i] = act_bufld4_aux<YUNET_BWD64_X_AUX>(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes);
             }
         }
     };
@@ -1868,14 +1875,16 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     float4 v = *reinterpret_cast<const float4*>(s_p + ip * XP + ((ich4 * 4) ^ tile_swz(ip)));
                     const float4 o = *reinterpret_cast<const float4*>(&old[i]);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, YUNET_DX_AUX);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     const int ip = tid / C4 + PSTEP * i;
                     const float4 v = *reinterpret_cast<const float4*>(s_p + ip * XP + ((ich4 * 4) ^ tile_swz(ip)));
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                    // (non-temporal on the big maps, default policy on the packed 20 x 20 / 10 x 10 levels: common.h)
+                    if constexpr (PACKED) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), r_dx, off[i], 0, YUNET_DX_AUX);
                 }
             }
         }

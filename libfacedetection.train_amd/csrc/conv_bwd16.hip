@@ -28,6 +28,14 @@
 // byte per element when the unit feeds max_pool2d: YunetDP.pool_idx) and dx -- z is not read.
 #include "common.h"
 
+// cache-policy bits of the streamed loads (measurement switches, round 6; 2 = non-temporal)
+#ifndef YUNET_BWD16_X_AUX
+#define YUNET_BWD16_X_AUX 0
+#endif
+#ifndef YUNET_BWD16_DY_AUX
+#define YUNET_BWD16_DY_AUX 0
+#endif
+
 namespace {
 namespace b16s {
 constexpr int C = 16, PXW = 32, HALO = 2, OUTW = PXW - 2 * HALO;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
             const bool yin = (unsigned)y < (unsigned)H;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                lx[t] = act_bufld4(r_x, (yin && colvP(t)) ? (unsigned)((y * W + colP(t)) * C + 4 * g) * ACT_B : xbytes);
+                lx[t] = act_bufld4_aux<YUNET_BWD16_X_AUX>(r_x, (yin && colvP(t)) ? (unsigned)((y * W + colP(t)) * C + 4 * g) * ACT_B : xbytes);
         };
         auto issue_dy = [&](int y) {
             const bool yin = (unsigned)y < (unsigned)H;
@@ -176,10 +184,10 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
                 const bool ok = yin && colvP(t);
                 if constexpr (POOLDY) {
                     const unsigned eq = (unsigned)(((y >> 1) * Wq + (colP(t) >> 1)) * C + 4 * g);
-                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, 0);
+                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eq * 4u : pooledbytes, 0, YUNET_BWD16_DY_AUX);
                     lid[t] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
                 } else {
-                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? (unsigned)((y * W + colP(t)) * C + 4 * g) * 4u : gbytes, 0, 0);
+                    ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? (unsigned)((y * W + colP(t)) * C + 4 * g) * 4u : gbytes, 0, YUNET_BWD16_DY_AUX);
                 }
             }
         };
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(b16s::NTHR, 1) void dp_bwd16s_kernel(const YunetDP 
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_dx,
-                                                           ownP(t) ? (unsigned)((r * W + colP(t)) * C + gq) * 4u : gbytes, 0, 0);
+                                                           ownP(t) ? (unsigned)((r * W + colP(t)) * C + gq) * 4u : gbytes, 0, YUNET_DX_AUX);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void dp_fwd_kernel(const YunetDP d, const Pack
                     if (!(abl & 4)) {
                         const unsigned zoff = (unsigned)(pn * (PACKED ? d.z_img_stride : 0) + (py * W + px) * COUT + cq * 4);
                         if (z_f32)
-                            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z, zoff * 4u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), r_z, zoff * 4u, 0, YUNET_ST_AUX);
                         else
                             act_bufst4(r_z, zoff * ACT_B, o);
                     }
