@@ -16,6 +16,10 @@
 
 namespace {
 
+// cache-policy bits of the generic tile kernel's x loads on unpacked maps (x is read once: tile interior only; 2 = non-temporal)
+#ifndef YUNET_BWDT_X_AUX
+#define YUNET_BWDT_X_AUX 0
+#endif
 #define BWD_THREADS 512
 #define BWD_WAVES 8
 // Where the split-bf16 variant issues the next tile's global loads: 1 = right after the stage (the
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
             } else {
                 off = (FULL || (y < H && x < W)) ? (unsigned)((y * W + x) * CIN + ich4 * 4) * ACT_B : xbytes;
             }
-            px[i] = act_bufld4(r_x, off);
+            px[i] = PACKED ? act_bufld4(r_x, off) : act_bufld4_aux<YUNET_BWDT_X_AUX>(r_x, off);
             if constexpr (PACKED) __builtin_amdgcn_sched_barrier(0);
         }
     };

@@ -16,6 +16,9 @@
 // 16-byte stores.  POOL (16 -> 16 units that feed max_pool2d only, YunetDP.pool_out): the 2 x 2 winners after BN + ReLU
 // and their window positions (dp_fwd_kernel<..., POOL>'s rule), from column pairs a lane owns and the row pair a band holds.
 #include "common.h"
+#ifndef YUNET_FWD16_X_AUX       // cache-policy bits of the x loads (round 6 measurement switch; 2 = non-temporal)
+#define YUNET_FWD16_X_AUX 0
+#endif
 
 namespace {
 namespace f16s {
@@ -121,7 +124,7 @@ void dp_fwd16s_kernel(const YunetDP d, const int R) {
             const bool yin = (unsigned)y < (unsigned)H;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                lx[nt] = act_bufld4(r_x, (yin && (unsigned)colP(nt) < (unsigned)W) ? (unsigned)((y * W + colP(nt)) * CIN + 4 * g) * ACT_B : xbytes);
+                lx[nt] = act_bufld4_aux<YUNET_FWD16_X_AUX>(r_x, (yin && (unsigned)colP(nt) < (unsigned)W) ? (unsigned)((y * W + colP(nt)) * CIN + 4 * g) * ACT_B : xbytes);
         };
         issue_x(y0 - 1);
         float ts0 = 0.0f, ts1 = 0.0f;                         // BN sums of the band: channel cc over the lane's output pixels

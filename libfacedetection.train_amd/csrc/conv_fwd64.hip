@@ -31,6 +31,9 @@
 // and bf16(W1) (fp32 accumulation) instead of the exact three-way split -- the arithmetic of the bf16 tile kernel
 // (conv_fwd.hip); depthwise, bias and BN sums (of the unrounded values) stay fp32.
 #include "common.h"
+#ifndef YUNET_FWD64_X_AUX       // cache-policy bits of the x loads (round 6 measurement switch; 2 = non-temporal)
+#define YUNET_FWD64_X_AUX 0
+#endif
 
 namespace {
 namespace f64s {
@@ -183,13 +186,13 @@ __device__ __forceinline__ void dp_fwd64s_body(const YunetDP& d, const int R, co
             if (abl & 8) return;
             const unsigned o = xlane + (unsigned)(y * W * C) * ACT_B;
 #ifdef YUNET_ACT_BF16
-            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, 0);          // 8 bf16 channels of block 0
-            xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 64, 0, 0);     // ... of block 1
+            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, YUNET_FWD64_X_AUX);          // 8 bf16 channels of block 0
+            xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 64, 0, YUNET_FWD64_X_AUX);     // ... of block 1
 #else
-            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, 0);
-            xr[1] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 16, 0, 0);
-            xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 128, 0, 0);
-            xr[3] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 144, 0, 0);
+            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o, 0, YUNET_FWD64_X_AUX);
+            xr[1] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 16, 0, YUNET_FWD64_X_AUX);
+            xr[2] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 128, 0, YUNET_FWD64_X_AUX);
+            xr[3] = __builtin_amdgcn_raw_buffer_load_b128(r_x, o + 144, 0, YUNET_FWD64_X_AUX);
 #endif
         };
         issue(rs);

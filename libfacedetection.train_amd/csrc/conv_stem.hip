@@ -18,6 +18,9 @@
 //             matrix product with K = the strip's 32 pixels (dz transposed through a 2.5 KB LDS slot, the patch
 //             gathered in im2col order), db = sum dz.  Per output pixel it reads 48 B of image + 64 B of dy.
 #include "common.h"
+#ifndef YUNET_STEM_BWD_AUX      // cache-policy bits of the image / dy loads of the BACKWARD instance (round 6 measurement switch; 2 = non-temporal;
+#define YUNET_STEM_BWD_AUX 0    //  the forward's loads on the default policy: non-temporal forward loads measured +1 % on the step)
+#endif
 
 namespace {
 namespace stm {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
                 const bool ok = colok && (unsigned)iy < (unsigned)H;
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci)
-                    lrow[r][ci] = __builtin_amdgcn_raw_buffer_load_b64(r_img, ok ? (unsigned)((ci * H + iy) * W + colp) * 4u : img_bytes, 0, 0);
+                    lrow[r][ci] = __builtin_amdgcn_raw_buffer_load_b64(r_img, ok ? (unsigned)((ci * H + iy) * W + colp) * 4u : img_bytes, 0, BWD ? YUNET_STEM_BWD_AUX : 0);
             }
         };
         u32x4 ldy[2];
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
             for (int t = 0; t < 2; ++t) {
                 const int ox = xo0 + 16 * t + l15;
                 ldy[t] = __builtin_amdgcn_raw_buffer_load_b128(
-                    r_z, (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * C + 4 * g) * 4u : zbytes, 0, 0);
+                    r_z, (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * C + 4 * g) * 4u : zbytes, 0, YUNET_STEM_BWD_AUX);
             }
         };
         // prologue: input row 2 y0 - 1 into its ring slot, rows 2 y0, 2 y0 + 1 in flight
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(stm::NTHR) void stem_mma_kernel(const float* __rest
             u32x2 v[3];
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
-                v[ci] = __builtin_amdgcn_raw_buffer_load_b64(r_img, ok ? (unsigned)((ci * H + iy) * W + colp) * 4u : img_bytes, 0, 0);
+                v[ci] = __builtin_amdgcn_raw_buffer_load_b64(r_img, ok ? (unsigned)((ci * H + iy) * W + colp) * 4u : img_bytes, 0, BWD ? YUNET_STEM_BWD_AUX : 0);
             issue_rows(y0);
             if constexpr (BWD) issue_dy(y0);
             if (lane < COLS / 2) {
