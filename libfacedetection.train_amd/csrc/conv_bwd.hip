@@ -1038,6 +1038,9 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
 #ifndef YUNET_BWD64_SWZ
 #define YUNET_BWD64_SWZ 1
 #endif
+#ifndef YUNET_BWD64_FAKE_LD
+#define YUNET_BWD64_FAKE_LD 0
+#endif
 #ifndef YUNET_BWD64_X_AUX        // cache-policy bits of the x loads of the unpacked instances: x is read exactly once (tile interior only),
                                  // non-temporal keeps it out of the L2 the dy / z halo re-reads live in (step -0.04 ms, profiles/r06_bench_ab_ntx.log)
 #define YUNET_BWD64_X_AUX 2
@@ -1328,11 +1331,25 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
                 pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
             } else {
+#if YUNET_BWD64_FAKE_LD == 1 // measurement build: every address is computed and kept alive, no load is issued (results wrong)
+                { unsigned o_ = ok ? eo * 4u : dybytes; asm volatile("" ::"v"(o_)); }
+#elif YUNET_BWD64_FAKE_LD == 2   // measurement build: the same number of load instructions, 4 bytes per lane instead of 16
+                { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eo * 4u : dybytes, 0, 0);
+                  pdy[i] = make_float4(__uint_as_float(w_), __uint_as_float(w_), __uint_as_float(w_), __uint_as_float(w_)); }
+#else
                 const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dybytes, 0, YUNET_BWD64_DY_AUX);
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
+#endif
             }
+#if YUNET_BWD64_FAKE_LD == 1
+            { unsigned o_ = ok ? eo * ACT_B : zbytes; asm volatile("" ::"v"(o_)); }
+#elif YUNET_BWD64_FAKE_LD == 2
+            { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_z, ok ? eo * ACT_B : zbytes, 0, 0);
+              pz[i] = act_raw4{w_, w_, w_, w_}; }
+#else
             pz[i] = act_raw4{};
             if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zbytes);
+#endif
         };
         auto body = [&](auto inner_c) {
             constexpr bool INNER = decltype(inner_c)::value;
@@ -1383,7 +1400,14 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const bool ok = tfull || (y0 + 2 * i + r < H && x0 + hxm < W);
+#if YUNET_BWD64_FAKE_LD == 1
+                { unsigned o_ = ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes; asm volatile("" ::"v"(o_)); }
+#elif YUNET_BWD64_FAKE_LD == 2
+                { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes, 0, 0);
+                  px[i] = act_raw4{w_, w_, w_, w_}; }
+#else
                 px[i] = act_bufld4_aux<YUNET_BWD64_X_AUX>(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes);
+#endif
             }
         }
     };
