@@ -1048,8 +1048,8 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
 #ifndef YUNET_BWD64_DY_AUX       // cache-policy bits of the dy loads (measurement switch; 0 = default policy; the dx stores: common.h YUNET_DX_AUX)
 #define YUNET_BWD64_DY_AUX 0
 #endif
-#ifndef YUNET_BWD64_PFMODE      // measurement switch: 1 = the next tile's loads issued at once (after the p GEMM)
-#define YUNET_BWD64_PFMODE 0
+#ifndef YUNET_BWD64_PFMODE      // where the next tile's loads are issued: 0 = four pieces from the p GEMM on (rounds 2-5), 1 = all at
+#define YUNET_BWD64_PFMODE 5    // once after the p GEMM (measurement), 5 = four pieces, each one issue point later (round 6)
 #endif
 namespace bwd64 {
 __device__ __forceinline__ int tile_swz(int pixel) { return YUNET_BWD64_SWZ ? ((pixel >> 2) & 1) << 4 : 0; }
@@ -1411,6 +1411,12 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
     };
+    // round 6: every piece one issue point LATER than in rounds 2-5 (x after the depthwise phase ... the last third of dy / z
+    // between the da GEMM and the mask): the requests spend less time queued in a memory system that is already
+    // oversubscribed by 256 CUs prefetching a whole tile each -- issuing EARLIER (inside the stage, into the registers it
+    // frees: built, +23 %) or all at once (+3 %) is worse, later is neutral at 80 x 80 and -1 .. -3 % on the smaller maps
+    // (profiles/r06_bwd64_pf5.log; -DYUNET_BWD64_PFMODE=0 = the earlier points)
+    constexpr bool LATE = (YUNET_BWD64_PFMODE == 5);
     auto issue_any = [&](int t, auto part_c) {
         if constexpr (ADDR2) issue2(t, part_c);
         else issue(t, part_c);
@@ -1668,7 +1674,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #if YUNET_BWD64_PFMODE == 1     // experiment: the whole next tile at once
         if (more) issue_any(t + gridDim.x, All{});
 #else
-        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 0>{});
+        if (more && !LATE) issue_any(t + gridDim.x, std::integral_constant<int, 0>{});
 #endif
 
         // ---- depthwise backward on the VALU (sliding window over a 4-row column); dp stays in registers -------------
@@ -1728,7 +1734,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
 #if YUNET_BWD64_PFMODE != 1
-        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 1>{});
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 0>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); }
 #endif
         __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
         {
@@ -1747,7 +1753,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         __syncthreads();
         DP_BWD64_STAMP(2);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 2>{});
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); }
 #endif
 
         // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
@@ -1791,7 +1797,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
         DP_BWD64_STAMP(3);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 3>{}); }
 #endif
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
@@ -1822,6 +1828,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (LATE && more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
             if (bn_in) {
                 const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
                 const float m_lo = s_ci[4 * C + c];
