@@ -31,6 +31,9 @@ namespace {
 #ifndef DP_BWD_PF_SPREAD
 #define DP_BWD_PF_SPREAD 1
 #endif
+#ifndef DP_BWD_PF_LATE              // round 6: every piece one issue point later (the last one between the da GEMM and the mask)
+#define DP_BWD_PF_LATE 0
+#endif
 #ifndef DP_BWD_PF_SPREAD_ALL        // also for the exact-fp32 variants (16 / 32-channel units)
 #define DP_BWD_PF_SPREAD_ALL 0
 #endif
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         __syncthreads();
         DP_BWD_STAMP(0);
         const bool more = t + (int)gridDim.x < ntiles && pf_on;
-        if (SPREAD) { if (more) issue(t + gridDim.x, std::integral_constant<int, 0>{}); }
+        if (SPREAD) { if (more && !DP_BWD_PF_LATE) issue(t + gridDim.x, std::integral_constant<int, 0>{}); }
         else if (GEMM == 1 && DP_BWD_PF_EARLY && more) issue(t + gridDim.x, All{});
 
         // ---- p = a * W1^T + b1 on the interior pixels (one M tile per wave) ---------------------
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         }
         __syncthreads();
         DP_BWD_STAMP(1);
-        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, 1>{});
+        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, DP_BWD_PF_LATE ? 0 : 1>{});
 
         // ---- depthwise backward on the VALU; dp overwrites p in place ----------------------------
         // A thread owns a channel quad and a column of PPT rows.  The dz column triple is walked
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         // prefetch the next tile's global data; issued here (not right after the stage) so that the
         // p GEMM and the VALU phase run without ~64 prefetch registers live -- the two GEMMs, the
         // mask phase and the store that follow are several microseconds, enough for HBM
-        if (SPREAD) { if (more) issue(t + gridDim.x, std::integral_constant<int, 2>{}); }
+        if (SPREAD) { if (more) issue(t + gridDim.x, std::integral_constant<int, DP_BWD_PF_LATE ? 1 : 2>{}); }
         else if (!(GEMM == 1 && DP_BWD_PF_EARLY) && more) issue(t + gridDim.x, All{});
 
         // ---- dW1 += a^T * dp (K = pixels) and da = dp * W1 on the matrix cores -------------------
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
                 for (int r = 0; r < 4; ++r) gw1[0][r] += (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
             }
         }
-        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
+        if (SPREAD && more) issue(t + gridDim.x, std::integral_constant<int, DP_BWD_PF_LATE ? 2 : 3>{});
         f32x4 da[G::MPW][G::NTI];
 #pragma unroll
         for (int mi = 0; mi < G::MPW; ++mi)
@@ -814,6 +817,7 @@ __global__ __launch_bounds__(BWD_THREADS) void dp_bwd_kernel(const YunetDP d, co
         }
         __syncthreads();  // every wave is done reading s_a for dW1
         DP_BWD_STAMP(3);
+        if (SPREAD && DP_BWD_PF_LATE && more) issue(t + gridDim.x, std::integral_constant<int, 3>{});
         if (bn_in) {
 #pragma unroll
             for (int nt = 0; nt < G::NTI; ++nt) {
@@ -1212,7 +1216,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xrange, 0x00020000);
-        if (PART <= 0) { okmask = 0; posmask = 0; }
+        if (PART < 0 || PART == (YUNET_BWD64_PFMODE == 6 ? 1 : 0)) { okmask = 0; posmask = 0; }
 #pragma unroll
         for (int i = 0; i < NDZ; ++i) {
             if (PART >= 0 && PART != 1 + (3 * i) / NDZ) continue;
@@ -1319,7 +1323,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xbytes, 0x00020000);
         const bool inner = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + TW < W;      // uniform: the halo is inside the image
-        if (PART <= 0) okmask = 0;
+        if (PART < 0 || PART == (YUNET_BWD64_PFMODE == 6 ? 1 : 0)) okmask = 0;
         const int tm = (r * W + hxm) * C + och4 * 4;              // elements from slot (row 0, column 0) of a pass
         const int hbase = ((y0 - 1) * W + (x0 - 1)) * C;          // halo origin (negative on the top / left border: masked)
         // pooled dy: halo slot (hy, hx) reads the pooled element ((y0 - 1 + hy) >> 1, (x0 - 1 + hx) >> 1); y0, x0 even
@@ -1416,7 +1420,8 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     // oversubscribed by 256 CUs prefetching a whole tile each -- issuing EARLIER (inside the stage, into the registers it
     // frees: built, +23 %) or all at once (+3 %) is worse, later is neutral at 80 x 80 and -1 .. -3 % on the smaller maps
     // (profiles/r06_bwd64_pf5.log; -DYUNET_BWD64_PFMODE=0 = the earlier points)
-    constexpr bool LATE = (YUNET_BWD64_PFMODE == 5);
+    constexpr bool LATE = (YUNET_BWD64_PFMODE == 5) || (YUNET_BWD64_PFMODE == 6);
+    constexpr int P0 = YUNET_BWD64_PFMODE == 6 ? 1 : 0, P1 = YUNET_BWD64_PFMODE == 6 ? 2 : 1, P2 = YUNET_BWD64_PFMODE == 6 ? 3 : 2, P3 = YUNET_BWD64_PFMODE == 6 ? 0 : 3;   // (6: x last, measurement)
     auto issue_any = [&](int t, auto part_c) {
         if constexpr (ADDR2) issue2(t, part_c);
         else issue(t, part_c);
@@ -1734,7 +1739,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 0>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P0>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); }
 #endif
         __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
         {
@@ -1753,7 +1758,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         __syncthreads();
         DP_BWD64_STAMP(2);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P1>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); }
 #endif
 
         // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
@@ -1797,7 +1802,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
         DP_BWD64_STAMP(3);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 3>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P2>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 3>{}); }
 #endif
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
@@ -1828,7 +1833,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (LATE && more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
+            if (LATE && more) issue_any(t + gridDim.x, std::integral_constant<int, P3>{});
             if (bn_in) {
                 const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
                 const float m_lo = s_ci[4 * C + c];
