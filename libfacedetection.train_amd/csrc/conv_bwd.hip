@@ -1042,9 +1042,6 @@ __device__ __forceinline__ float act_bufld1(R rsrc, unsigned byte_off) {
 #ifndef YUNET_BWD64_SWZ
 #define YUNET_BWD64_SWZ 1
 #endif
-#ifndef YUNET_BWD64_FAKE_LD
-#define YUNET_BWD64_FAKE_LD 0
-#endif
 #ifndef YUNET_BWD64_X_AUX        // cache-policy bits of the x loads of the unpacked instances: x is read exactly once (tile interior only),
                                  // non-temporal keeps it out of the L2 the dy / z halo re-reads live in (step -0.04 ms, profiles/r06_bench_ab_ntx.log)
 #define YUNET_BWD64_X_AUX 2
@@ -1216,7 +1213,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             reinterpret_cast<act_t*>(const_cast<float*>(d.z)) + zbase, 0, zrange, 0x00020000);
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xrange, 0x00020000);
-        if (PART < 0 || PART == (YUNET_BWD64_PFMODE == 6 ? 1 : 0)) { okmask = 0; posmask = 0; }
+        if (PART <= 0) { okmask = 0; posmask = 0; }
 #pragma unroll
         for (int i = 0; i < NDZ; ++i) {
             if (PART >= 0 && PART != 1 + (3 * i) / NDZ) continue;
@@ -1323,7 +1320,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         const auto r_x = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<act_t*>(const_cast<float*>(d.x)) + xbase, 0, xbytes, 0x00020000);
         const bool inner = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + TW < W;      // uniform: the halo is inside the image
-        if (PART < 0 || PART == (YUNET_BWD64_PFMODE == 6 ? 1 : 0)) okmask = 0;
+        if (PART <= 0) okmask = 0;
         const int tm = (r * W + hxm) * C + och4 * 4;              // elements from slot (row 0, column 0) of a pass
         const int hbase = ((y0 - 1) * W + (x0 - 1)) * C;          // halo origin (negative on the top / left border: masked)
         // pooled dy: halo slot (hy, hx) reads the pooled element ((y0 - 1 + hy) >> 1, (x0 - 1 + hx) >> 1); y0, x0 even
@@ -1335,25 +1332,11 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
                 pid[i] = __builtin_amdgcn_raw_buffer_load_b32(r_id, ok ? eq : pooledbytes, 0, 0);
             } else {
-#if YUNET_BWD64_FAKE_LD == 1 // measurement build: every address is computed and kept alive, no load is issued (results wrong)
-                { unsigned o_ = ok ? eo * 4u : dybytes; asm volatile("" ::"v"(o_)); }
-#elif YUNET_BWD64_FAKE_LD == 2   // measurement build: the same number of load instructions, 4 bytes per lane instead of 16
-                { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_dy, ok ? eo * 4u : dybytes, 0, 0);
-                  pdy[i] = make_float4(__uint_as_float(w_), __uint_as_float(w_), __uint_as_float(w_), __uint_as_float(w_)); }
-#else
                 const u32x4 vdy = __builtin_amdgcn_raw_buffer_load_b128(r_dy, ok ? eo * 4u : dybytes, 0, YUNET_BWD64_DY_AUX);
                 pdy[i] = *reinterpret_cast<const float4*>(&vdy);
-#endif
             }
-#if YUNET_BWD64_FAKE_LD == 1
-            { unsigned o_ = ok ? eo * ACT_B : zbytes; asm volatile("" ::"v"(o_)); }
-#elif YUNET_BWD64_FAKE_LD == 2
-            { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_z, ok ? eo * ACT_B : zbytes, 0, 0);
-              pz[i] = act_raw4{w_, w_, w_, w_}; }
-#else
             pz[i] = act_raw4{};
             if (bn_out) pz[i] = act_bufld4(r_z, ok ? eo * ACT_B : zbytes);
-#endif
         };
         auto body = [&](auto inner_c) {
             constexpr bool INNER = decltype(inner_c)::value;
@@ -1404,14 +1387,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const bool ok = tfull || (y0 + 2 * i + r < H && x0 + hxm < W);
-#if YUNET_BWD64_FAKE_LD == 1
-                { unsigned o_ = ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes; asm volatile("" ::"v"(o_)); }
-#elif YUNET_BWD64_FAKE_LD == 2
-                { const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes, 0, 0);
-                  px[i] = act_raw4{w_, w_, w_, w_}; }
-#else
                 px[i] = act_bufld4_aux<YUNET_BWD64_X_AUX>(r_x, ok ? (unsigned)(xb + i * 2 * W * C + tm) * ACT_B : xbytes);
-#endif
             }
         }
     };
@@ -1420,8 +1396,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
     // oversubscribed by 256 CUs prefetching a whole tile each -- issuing EARLIER (inside the stage, into the registers it
     // frees: built, +23 %) or all at once (+3 %) is worse, later is neutral at 80 x 80 and -1 .. -3 % on the smaller maps
     // (profiles/r06_bwd64_pf5.log; -DYUNET_BWD64_PFMODE=0 = the earlier points)
-    constexpr bool LATE = (YUNET_BWD64_PFMODE == 5) || (YUNET_BWD64_PFMODE == 6);
-    constexpr int P0 = YUNET_BWD64_PFMODE == 6 ? 1 : 0, P1 = YUNET_BWD64_PFMODE == 6 ? 2 : 1, P2 = YUNET_BWD64_PFMODE == 6 ? 3 : 2, P3 = YUNET_BWD64_PFMODE == 6 ? 0 : 3;   // (6: x last, measurement)
+    constexpr bool LATE = (YUNET_BWD64_PFMODE == 5);
     auto issue_any = [&](int t, auto part_c) {
         if constexpr (ADDR2) issue2(t, part_c);
         else issue(t, part_c);
@@ -1739,7 +1714,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
             }
         }
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P0>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 0>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); }
 #endif
         __syncthreads();      // every dz read is done: the dp planes may overwrite the halo
         {
@@ -1758,7 +1733,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         __syncthreads();
         DP_BWD64_STAMP(2);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P1>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 1>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); }
 #endif
 
         // ---- dW1 += a^T * dp (K = pixels): operands through the transposing LDS read --------------------------------
@@ -1802,7 +1777,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
         }
         DP_BWD64_STAMP(3);
 #if YUNET_BWD64_PFMODE != 1
-        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, P2>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 3>{}); }
+        if (more) { if (LATE) issue_any(t + gridDim.x, std::integral_constant<int, 2>{}); else issue_any(t + gridDim.x, std::integral_constant<int, 3>{}); }
 #endif
 
         // ---- da = dp * W1 (this wave's 16 input channels, 4 pixel tiles) + ReLU mask + BN-backward sums ----------------
@@ -1833,7 +1808,7 @@ void dp_bwd64_kernel(const YunetDP d, const PackGeom pk) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (LATE && more) issue_any(t + gridDim.x, std::integral_constant<int, P3>{});
+            if (LATE && more) issue_any(t + gridDim.x, std::integral_constant<int, 3>{});
             if (bn_in) {
                 const float m_mean = s_ci[c], m_scale = s_ci[C + c], m_beta = s_ci[2 * C + c], m_inv = s_ci[3 * C + c];
                 const float m_lo = s_ci[4 * C + c];
